@@ -1,0 +1,221 @@
+// HBM-bound elementwise / reduction kernels of the energy-grid engine (gfx950).
+//   assemble   : A_b = E_b S - H - Sigma_b            (integrate.py:70, transport.py:153)
+//   accumulate : acc += sum_b w_b X_b                 (integrate.py:105,119)
+//   trace_dot  : Re sum_ij X_ij conj(G_ij)            (transport.py:157 -- Tr[X G^H])
+//   dos        : -Im diag(G)/pi and its sum           (transport.py:188-189, density.py:54)
+// All accesses are 16-byte (one complex128) per lane, consecutive lanes on
+// consecutive elements -> fully coalesced 1 KiB wave transactions.
+#include "negf_common.h"
+
+static constexpr int EW_THREADS = 256;
+
+// ---------------------------------------------------------------- assemble
+__global__ __launch_bounds__(EW_THREADS) void assemble_kernel(
+    int n2, const cplx* __restrict__ E, const cplx* __restrict__ S, const cplx* __restrict__ H,
+    const cplx* __restrict__ sig_dense, cplx* __restrict__ A)
+{
+    const int b = blockIdx.y;
+    const cplx e = E[b];
+    const size_t base = (size_t)b * n2;
+    for (int i = blockIdx.x * EW_THREADS + threadIdx.x; i < n2; i += gridDim.x * EW_THREADS) {
+        const cplx s = S[i];
+        const cplx h = H[i];
+        // (E*S - H) - Sigma, the reference's evaluation order (integrate.py:70)
+        cplx a = cmake(e.x * s.x - e.y * s.y - h.x, e.x * s.y + e.y * s.x - h.y);
+        if (sig_dense) a = csub(a, sig_dense[base + i]);
+        A[base + i] = a;
+    }
+}
+
+// A_b[inds_c[i]][inds_c[j]] -= blk_b[c][i][j]   (one block per (contact, energy))
+__global__ __launch_bounds__(EW_THREADS) void scatter_sub_kernel(
+    int n, const cplx* __restrict__ blk, int blk_stride, const int* __restrict__ d_nc,
+    const int* __restrict__ d_blk_off, const int* __restrict__ d_inds_off,
+    const int* __restrict__ d_inds, cplx* __restrict__ A)
+{
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int nc = d_nc[c];
+    const int* inds = d_inds + d_inds_off[c];
+    const cplx* src = blk + (size_t)b * blk_stride + d_blk_off[c];
+    cplx* dst = A + (size_t)b * n * n;
+    for (int t = threadIdx.x; t < nc * nc; t += EW_THREADS) {
+        const int i = t / nc, j = t - i * nc;
+        const size_t o = (size_t)inds[i] * n + inds[j];
+        dst[o] = csub(dst[o], src[t]);
+    }
+}
+
+void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S, const cplx* H,
+                     const cplx* sig_dense, const cplx* blk, int blk_stride, int n_contacts,
+                     const int* d_nc, const int* d_blk_off, const int* d_inds_off,
+                     const int* d_inds, cplx* A)
+{
+    const int n2 = n * n;
+    int gx = (n2 + EW_THREADS - 1) / EW_THREADS;
+    if (gx > 64) gx = 64;                          // grid-stride the rest
+    hipLaunchKernelGGL(assemble_kernel, dim3(gx, nb), dim3(EW_THREADS), 0, st, n2, E, S, H,
+                       sig_dense, A);
+    if (blk && n_contacts > 0) {
+        // contacts may share orbitals, so blocks are subtracted one contact at a
+        // time (stream order) instead of racing on the same element
+        for (int c = 0; c < n_contacts; ++c)
+            hipLaunchKernelGGL(scatter_sub_kernel, dim3(1, nb), dim3(EW_THREADS), 0, st, n, blk,
+                               blk_stride, d_nc + c, d_blk_off + c, d_inds_off + c, d_inds, A);
+    }
+}
+
+// out_b = scatter-add of contact blocks into a zeroed n x n matrix
+__global__ __launch_bounds__(EW_THREADS) void zero_kernel(size_t count, cplx* __restrict__ p)
+{
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * EW_THREADS)
+        p[i] = cmake(0.0, 0.0);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void scatter_add_kernel(
+    int n, const cplx* __restrict__ blk, int blk_stride, const int* __restrict__ d_nc,
+    const int* __restrict__ d_blk_off, const int* __restrict__ d_inds_off,
+    const int* __restrict__ d_inds, cplx* __restrict__ out)
+{
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int nc = d_nc[c];
+    const int* inds = d_inds + d_inds_off[c];
+    const cplx* src = blk + (size_t)b * blk_stride + d_blk_off[c];
+    cplx* dst = out + (size_t)b * n * n;
+    for (int t = threadIdx.x; t < nc * nc; t += EW_THREADS) {
+        const int i = t / nc, j = t - i * nc;
+        const size_t o = (size_t)inds[i] * n + inds[j];
+        dst[o] = cadd(dst[o], src[t]);
+    }
+}
+
+void launch_scatter_blocks(hipStream_t st, int n, int nb, const cplx* blk, int blk_stride,
+                           int n_contacts, const int* d_nc, const int* d_blk_off,
+                           const int* d_inds_off, const int* d_inds, int contact, cplx* out)
+{
+    const size_t count = (size_t)nb * n * n;
+    int g = (int)((count + EW_THREADS - 1) / EW_THREADS);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(zero_kernel, dim3(g), dim3(EW_THREADS), 0, st, count, out);
+    const int c0 = contact < 0 ? 0 : contact;
+    const int c1 = contact < 0 ? n_contacts : contact + 1;
+    for (int c = c0; c < c1; ++c)
+        hipLaunchKernelGGL(scatter_add_kernel, dim3(1, nb), dim3(EW_THREADS), 0, st, n, blk,
+                           blk_stride, d_nc + c, d_blk_off + c, d_inds_off + c, d_inds, out);
+}
+
+// ------------------------------------------------------------------- gamma
+// Gamma = i (Sigma - Sigma^H)   (integrate.py:80, transport.py:146)
+__global__ __launch_bounds__(EW_THREADS) void gamma_kernel(
+    int n, const cplx* __restrict__ sig, size_t stride_sig, cplx* __restrict__ gam)
+{
+    const int b = blockIdx.y;
+    const cplx* s = sig + (size_t)b * stride_sig;
+    cplx* g = gam + (size_t)b * n * n;
+    const int n2 = n * n;
+    for (int t = blockIdx.x * EW_THREADS + threadIdx.x; t < n2; t += gridDim.x * EW_THREADS) {
+        const int i = t / n, j = t - i * n;
+        const cplx a = s[t];
+        const cplx bt = s[(size_t)j * n + i];
+        // d = a - conj(bt); i*d = (-d.y, d.x)
+        const double dx = a.x - bt.x, dy = a.y + bt.y;
+        g[t] = cmake(-dy, dx);
+    }
+}
+
+void launch_gamma_dense(hipStream_t st, int n, int nb, const cplx* sig, size_t stride_sig, cplx* gam)
+{
+    int gx = (n * n + EW_THREADS - 1) / EW_THREADS;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gamma_kernel, dim3(gx, nb), dim3(EW_THREADS), 0, st, n, sig, stride_sig, gam);
+}
+
+// -------------------------------------------------------------- accumulate
+// acc[i] += sum_b w[b] * X[b][i], b ascending inside one thread -> the summation
+// order over energies is fixed (bitwise reproducible from run to run).
+__global__ __launch_bounds__(EW_THREADS) void accumulate_kernel(
+    int n2, int nb, const cplx* __restrict__ w, const cplx* __restrict__ X, cplx* __restrict__ acc)
+{
+    const int i = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= n2) return;
+    cplx a = acc[i];
+    for (int b = 0; b < nb; ++b) a = cfma(a, w[b], X[(size_t)b * n2 + i]);
+    acc[i] = a;
+}
+
+void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc)
+{
+    const int g = (n2 + EW_THREADS - 1) / EW_THREADS;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nb, w, X, acc);
+}
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// one workgroup per energy: Re sum X_ij conj(G_ij) = sum (Xr Gr + Xi Gi)
+__global__ __launch_bounds__(EW_THREADS) void trace_dot_kernel(
+    int nr, int ncol, const cplx* __restrict__ X, int ldx, size_t strideX,
+    const cplx* __restrict__ G, int ldg, size_t strideG, double* __restrict__ out, int out_stride)
+{
+    __shared__ double part[EW_THREADS / 64];
+    const int b = blockIdx.x;
+    const cplx* x = X + (size_t)b * strideX;
+    const cplx* g = G + (size_t)b * strideG;
+    double s = 0.0;
+    const int total = nr * ncol;
+    for (int t = threadIdx.x; t < total; t += EW_THREADS) {
+        const int i = t / ncol, j = t - i * ncol;
+        const cplx a = x[(size_t)i * ldx + j];
+        const cplx c = g[(size_t)i * ldg + j];
+        s += a.x * c.x + a.y * c.y;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < EW_THREADS / 64; ++k) t += part[k];
+        out[(size_t)b * out_stride] = t;
+    }
+}
+
+void launch_trace_dot(hipStream_t st, int nr, int ncol, int nb, const cplx* X, int ldx,
+                      size_t strideX, const cplx* G, int ldg, size_t strideG, double* out,
+                      int out_stride)
+{
+    hipLaunchKernelGGL(trace_dot_kernel, dim3(nb), dim3(EW_THREADS), 0, st, nr, ncol, X, ldx,
+                       strideX, G, ldg, strideG, out, out_stride);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void dos_kernel(
+    int n, const cplx* __restrict__ G, double* __restrict__ dos_tot, double* __restrict__ dos_site)
+{
+    __shared__ double part[EW_THREADS / 64];
+    const int b = blockIdx.x;
+    const cplx* g = G + (size_t)b * n * n;
+    const double pi = 3.14159265358979323846;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += EW_THREADS) {
+        const double d = -g[(size_t)i * n + i].y / pi;      // same rounding as -imag/np.pi
+        if (dos_site) dos_site[(size_t)b * n + i] = d;
+        s += d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < EW_THREADS / 64; ++k) t += part[k];
+        dos_tot[b] = t;
+    }
+}
+
+void launch_dos(hipStream_t st, int n, int nb, const cplx* G, double* dos_tot, double* dos_site)
+{
+    hipLaunchKernelGGL(dos_kernel, dim3(nb), dim3(EW_THREADS), 0, st, n, G, dos_tot, dos_site);
+}

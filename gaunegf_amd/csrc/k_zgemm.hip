@@ -1,0 +1,240 @@
+// Batched complex128 GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+//   C_b (M x N) = A_b (M x K) * op(B_b),   op(B) = B  or  B^H
+//
+// used for the dense products of the lesser Green's function G Gamma G^H
+// (integrate.py:81) and of the transmission Gamma_L G Gamma_R (transport.py:156,
+// 176).  A complex product is four real MFMA chains per 16x16 tile:
+//   Cr += Ar*Br ; Cr += (-Ai)*Bi ; Ci += Ar*Bi ; Ci += Ai*Br
+// Fragment layout of v_mfma_f64_16x16x4_f64 (guide section 3):
+//   A operand: lane l holds A[i = l&15][k = l>>4]       (one f64 per lane)
+//   B operand: lane l holds B[k = l>>4][j = l&15]
+//   C/D      : lane l, register r holds C[row = (l>>4) + 4r][col = l&15]
+// Interleaved (re,im) storage means ONE 16-byte LDS read gives a lane both the
+// real and the imaginary operand of its element.
+//
+// Workgroup = 256 threads = 4 waves; block tile 64 x 64, wave tile 32 x 32
+// (2 x 2 MFMA tiles, 64 accumulator VGPRs), K tile 16 staged through LDS.
+#include "negf_common.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+static constexpr int ZG_BM = 64, ZG_BN = 64, ZG_BK = 16;
+static constexpr int ZG_APITCH = ZG_BK + 1;     // odd pitch: 16 rows -> 16 distinct 16-B slots
+static constexpr int ZG_BPITCH = ZG_BN + 1;
+
+__global__ __launch_bounds__(256) void zgemm_mfma_kernel(
+    int M, int N, int K,
+    const cplx* __restrict__ Aall, int lda, size_t strideA,
+    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
+    cplx* __restrict__ Call, int ldc, size_t strideC)
+{
+    __shared__ cplx As[ZG_BM * ZG_APITCH];      // As[i][k]
+    __shared__ cplx Bs[ZG_BK * ZG_BPITCH];      // Bs[k][j]  (already op()'ed)
+
+    const int b = blockIdx.z;
+    const cplx* A = Aall + (size_t)b * strideA;
+    const cplx* B = Ball + (size_t)b * strideB;
+    cplx* C = Call + (size_t)b * strideC;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.y * ZG_BM, col0 = blockIdx.x * ZG_BN;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;   // wave tile origin in the block tile
+    const int fi = lane & 15, fk = lane >> 4;
+
+    d4 accr[2][2], acci[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { accr[a][c] = (d4){0, 0, 0, 0}; acci[a][c] = (d4){0, 0, 0, 0}; }
+
+    // staging assignment: 64 rows x 16 cols, 4 consecutive elements per thread
+    const int lr = tid >> 2, lc = (tid & 3) * 4;         // A tile (and B^H tile): row lr, cols lc..lc+3
+    const int br = tid >> 4, bc = (tid & 15) * 4;        // B tile (opB=0): row br, cols bc..bc+3
+
+    for (int k0 = 0; k0 < K; k0 += ZG_BK) {
+        // ---- global -> LDS (zero fill outside the matrix)
+        {
+            const int gi = row0 + lr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gk = k0 + lc + e;
+                cplx v = cmake(0.0, 0.0);
+                if (gi < M && gk < K) v = A[(size_t)gi * lda + gk];
+                As[lr * ZG_APITCH + lc + e] = v;
+            }
+        }
+        if (opB == 0) {
+            const int gk = k0 + br;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gj = col0 + bc + e;
+                cplx v = cmake(0.0, 0.0);
+                if (gk < K && gj < N) v = B[(size_t)gk * ldb + gj];
+                Bs[br * ZG_BPITCH + bc + e] = v;
+            }
+        } else {
+            // op(B)[k][j] = conj(B[j][k]); B stored N x K
+            const int gj = col0 + lr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gk = k0 + lc + e;
+                cplx v = cmake(0.0, 0.0);
+                if (gj < N && gk < K) v = cconj(B[(size_t)gj * ldb + gk]);
+                Bs[(lc + e) * ZG_BPITCH + lr] = v;
+            }
+        }
+        __syncthreads();
+        // ---- 4 k-steps of 4
+#pragma unroll
+        for (int ks = 0; ks < ZG_BK; ks += 4) {
+            cplx af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = As[(wr + a * 16 + fi) * ZG_APITCH + ks + fk];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bf[c] = Bs[(ks + fk) * ZG_BPITCH + wc + c * 16 + fi];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].x, accr[a][c], 0, 0, 0);
+                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf[c].y, accr[a][c], 0, 0, 0);
+                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].y, acci[a][c], 0, 0, 0);
+                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf[c].x, acci[a][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // ---- store: lane l, reg r -> row (l>>4) + 4r, col l&15 ; 16 lanes write 256 contiguous bytes
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = row0 + wr + a * 16 + fk + 4 * r;
+                const int gj = col0 + wc + c * 16 + fi;
+                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(accr[a][c][r], acci[a][c][r]);
+            }
+}
+
+// Plain VALU version (no matrix cores): kept as the independent cross-check of
+// the MFMA fragment maps (tests compare the two) and selectable with
+// NEGF_ZGEMM_ALGO=valu for debugging.
+__global__ __launch_bounds__(256) void zgemm_valu_kernel(
+    int M, int N, int K,
+    const cplx* __restrict__ Aall, int lda, size_t strideA,
+    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
+    cplx* __restrict__ Call, int ldc, size_t strideC)
+{
+    __shared__ cplx As[32][17];
+    __shared__ cplx Bs[16][33];
+    const int b = blockIdx.z;
+    const cplx* A = Aall + (size_t)b * strideA;
+    const cplx* B = Ball + (size_t)b * strideB;
+    cplx* C = Call + (size_t)b * strideC;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;              // 16 x 16 threads, 2 x 2 outputs each
+    const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 32;
+    cplx acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) acc[a][c] = cmake(0.0, 0.0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int t = tid; t < 32 * 16; t += 256) {
+            const int i = t >> 4, k = t & 15;
+            cplx v = cmake(0.0, 0.0);
+            if (row0 + i < M && k0 + k < K) v = A[(size_t)(row0 + i) * lda + k0 + k];
+            As[i][k] = v;
+        }
+        for (int t = tid; t < 16 * 32; t += 256) {
+            cplx v = cmake(0.0, 0.0);
+            if (opB == 0) {
+                const int k = t >> 5, j = t & 31;
+                if (k0 + k < K && col0 + j < N) v = B[(size_t)(k0 + k) * ldb + col0 + j];
+                Bs[k][j] = v;
+            } else {
+                const int j = t >> 4, k = t & 15;
+                if (col0 + j < N && k0 + k < K) v = cconj(B[(size_t)(col0 + j) * ldb + k0 + k]);
+                Bs[k][j] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[a][c] = cfma(acc[a][c], As[ty + 16 * a][k], Bs[k][tx + 16 * c]);
+        __syncthreads();
+    }
+    for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 2; ++c) {
+            const int gi = row0 + ty + 16 * a, gj = col0 + tx + 16 * c;
+            if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = acc[a][c];
+        }
+}
+
+static int zgemm_algo()
+{
+    static int algo = -1;
+    if (algo < 0) {
+        const char* e = getenv("NEGF_ZGEMM_ALGO");
+        algo = (e && strcmp(e, "valu") == 0) ? 1 : 0;
+    }
+    return algo;
+}
+
+void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
+                  const cplx* A, int lda, size_t strideA,
+                  const cplx* B, int ldb, size_t strideB, int opB,
+                  cplx* C, int ldc, size_t strideC)
+{
+    if (M <= 0 || N <= 0 || nb <= 0) return;
+    if (zgemm_algo() == 1) {
+        dim3 grid((N + 31) / 32, (M + 31) / 32, nb);
+        hipLaunchKernelGGL(zgemm_valu_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
+                           strideB, opB, C, ldc, strideC);
+    } else {
+        dim3 grid((N + ZG_BN - 1) / ZG_BN, (M + ZG_BM - 1) / ZG_BM, nb);
+        hipLaunchKernelGGL(zgemm_mfma_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
+                           strideB, opB, C, ldc, strideC);
+    }
+}
+
+// ------------------------------------------------------------------ self test
+// One wave multiplies exact small-integer matrices A (16x4) and an ASYMMETRIC B
+// (4x16) with a single MFMA and compares against the exact integer product under
+// the documented fragment maps.  max_err must be exactly 0.
+__global__ void mfma_probe_kernel(double* __restrict__ err_out)
+{
+    const int lane = threadIdx.x;
+    const int i = lane & 15, k = lane >> 4;
+    // A[i][k] = i + 3k + 1 ; B[k][j] = 2j - 5k + (j*j)%7  (no symmetry)
+    const double a = (double)(i + 3 * k + 1);
+    const int j = lane & 15;
+    const double bval = (double)(2 * j - 5 * k + (j * j) % 7);
+    d4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bval, acc, 0, 0, 0);
+    double e = 0.0;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) + 4 * r, col = lane & 15;
+        double ref = 0.0;
+        for (int kk = 0; kk < 4; ++kk)
+            ref += (double)(row + 3 * kk + 1) * (double)(2 * col - 5 * kk + (col * col) % 7);
+        e = fmax(e, fabs(acc[r] - ref));
+    }
+    for (int off = 32; off > 0; off >>= 1) e = fmax(e, __shfl_down(e, off, 64));
+    if (lane == 0) err_out[0] = e;
+}
+
+int run_mfma_selftest(hipStream_t st, double* max_err)
+{
+    double* d = nullptr;
+    NEGF_HIP_CHECK(hipMalloc(&d, sizeof(double)));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, st, d);
+    NEGF_HIP_CHECK(hipGetLastError());
+    NEGF_HIP_CHECK(hipMemcpyAsync(max_err, d, sizeof(double), hipMemcpyDeviceToHost, st));
+    NEGF_HIP_CHECK(hipStreamSynchronize(st));
+    NEGF_HIP_CHECK(hipFree(d));
+    return NEGF_OK;
+}

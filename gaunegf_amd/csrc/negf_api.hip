@@ -1,0 +1,985 @@
+// C ABI of libnegf_hip.so (include/negf.h): context, self-energy providers and the
+// orchestration of the per-batch kernel sequence.  No compute happens on the
+// host here; there is no CPU fallback (negf_create fails without a GPU).
+#include "negf_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <new>
+
+static hipEvent_t prof_get_event(negf_ctx* c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(negf_ctx* ctx, const char* nm) : c(ctx), name(nm)
+{
+    if (!c->profiling) return;
+    e0 = prof_get_event(c); e1 = prof_get_event(c);
+    if (e0) (void)hipEventRecord(e0, c->stream);
+}
+
+ProfScope::~ProfScope()
+{
+    if (!c->profiling || !e0 || !e1) return;
+    (void)hipEventRecord(e1, c->stream);
+    c->prof_pending.push_back({name, e0, e1});
+}
+
+static void prof_resolve(negf_ctx* c)
+{
+    for (auto& p : c->prof_pending) {
+        (void)hipEventSynchronize(p.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            auto& e = c->prof[p.name]; e.ms += ms; e.launches += 1;
+        }
+        c->ev_pool.push_back(p.e0); c->ev_pool.push_back(p.e1);
+    }
+    c->prof_pending.clear();
+}
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) return NEGF_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return NEGF_ENOMEM; }
+    return NEGF_OK;
+}
+template <typename T>
+void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+template <typename T>
+int upload(negf_ctx* c, T* dst, const T* src, size_t count)
+{
+    if (count == 0) return NEGF_OK;
+    NEGF_HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));   // src may be freed by the caller on return
+    return NEGF_OK;
+}
+template <typename T>
+int download(negf_ctx* c, T* dst, const T* src, size_t count)
+{
+    if (count == 0) return NEGF_OK;
+    NEGF_HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return NEGF_OK;
+}
+
+void free_provider(SigmaProvider* p)
+{
+    if (!p) return;
+    dev_free(p->d_const_c); dev_free(p->d_const_tot); dev_free(p->d_hbase);
+    dev_free(p->d_inds); dev_free(p->d_nc); dev_free(p->d_blk_off); dev_free(p->d_inds_off);
+    dev_free(p->d_n_atoms); dev_free(p->d_atom_off);
+    dev_free(p->d_alpha); dev_free(p->d_Salpha); dev_free(p->d_beta); dev_free(p->d_Sbeta);
+    dev_free(p->d_tau); dev_free(p->d_Stau);
+    dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
+    dev_free(p->d_H); dev_free(p->d_Slist); dev_free(p->d_Vlist); dev_free(p->d_xi);
+    dev_free(p->d_pre_tot); dev_free(p->d_pre_c);
+    delete p;
+}
+
+void free_workspace(negf_ctx* c)
+{
+    dev_free(c->d_A); dev_free(c->d_T1); dev_free(c->d_T2); dev_free(c->d_blk);
+    dev_free(c->d_ipiv); dev_free(c->d_site); dev_free(c->d_scratch);
+    c->batch = 0; c->blk_cap = 0; c->scratch_cap = 0;
+}
+
+void free_mbuffers(negf_ctx* c)
+{
+    dev_free(c->d_info); dev_free(c->d_iters); dev_free(c->d_conv);
+    dev_free(c->d_E); dev_free(c->d_w); dev_free(c->d_scal);
+    c->m_cap = 0; c->contacts_cap = 0;
+}
+
+int auto_batch(negf_ctx* c, int m)
+{
+    if (c->batch_user > 0) return std::min(c->batch_user, std::max(m, 1));
+    // three n x n complex128 work matrices per in-flight energy; keep the working
+    // set within ~6 GB (a sliver of the 288 GB of HBM3E, enough to fill 256 CUs
+    // several times over) and never above the grid length
+    const double per = 3.0 * 16.0 * (double)c->n * (double)c->n;
+    long b = (long)(6.0e9 / std::max(per, 1.0));
+    b = std::max(1L, std::min(b, 4096L));
+    return (int)std::min<long>(b, std::max(m, 1));
+}
+
+int ensure_workspace(negf_ctx* c, int m, int blk_stride, int min_batch = 1)
+{
+    const int want = std::max(auto_batch(c, m), min_batch);
+    if (want > c->batch) {
+        free_workspace(c);
+        const size_t n2 = (size_t)c->n * c->n;
+        int rc;
+        if ((rc = dev_alloc(&c->d_A, n2 * want))) return rc;
+        if ((rc = dev_alloc(&c->d_T1, n2 * want))) return rc;
+        if ((rc = dev_alloc(&c->d_T2, n2 * want))) return rc;
+        if ((rc = dev_alloc(&c->d_ipiv, (size_t)c->n * want))) return rc;
+        if ((rc = dev_alloc(&c->d_site, (size_t)c->n * want))) return rc;
+        c->batch = want;
+    }
+    const int need_blk = blk_stride * c->batch;
+    if (need_blk > c->blk_cap) {
+        dev_free(c->d_blk);
+        int rc = dev_alloc(&c->d_blk, (size_t)need_blk);
+        if (rc) return rc;
+        c->blk_cap = need_blk;
+    }
+    return NEGF_OK;
+}
+
+int ensure_mbuffers(negf_ctx* c, int m, int contacts)
+{
+    contacts = std::max(contacts, 1);
+    if (m <= c->m_cap && contacts <= c->contacts_cap) return NEGF_OK;
+    const int mm = std::max(m, c->m_cap), cc = std::max(contacts, c->contacts_cap);
+    free_mbuffers(c);
+    int rc;
+    if ((rc = dev_alloc(&c->d_info, (size_t)mm))) return rc;
+    if ((rc = dev_alloc(&c->d_iters, (size_t)mm * cc))) return rc;
+    if ((rc = dev_alloc(&c->d_conv, (size_t)mm * cc))) return rc;
+    if ((rc = dev_alloc(&c->d_E, (size_t)mm))) return rc;
+    if ((rc = dev_alloc(&c->d_w, (size_t)mm))) return rc;
+    if ((rc = dev_alloc(&c->d_scal, (size_t)mm * 8))) return rc;
+    c->m_cap = mm; c->contacts_cap = cc;
+    return NEGF_OK;
+}
+
+SigmaProvider* get_provider(negf_ctx* c, int handle)
+{
+    if (!c || handle < 0 || handle >= (int)c->providers.size()) return nullptr;
+    return c->providers[handle];
+}
+
+int add_provider(negf_ctx* c, SigmaProvider* p)
+{
+    for (size_t i = 0; i < c->providers.size(); ++i)
+        if (!c->providers[i]) { c->providers[i] = p; return (int)i; }
+    c->providers.push_back(p);
+    return (int)c->providers.size() - 1;
+}
+
+// Python-style contact index normalisation; returns -1 for "total", -2 for invalid
+int norm_contact(const SigmaProvider* p, int ind)
+{
+    if (ind == NEGF_IND_TOTAL) return -1;
+    int nc = p->n_contacts;
+    if (p->kind == SK_PRECOMPUTED) nc = std::max(p->pre_nc, 1);
+    if (ind < 0) ind += nc;
+    if (ind < 0 || ind >= nc) return -2;
+    return ind;
+}
+
+void run_inverse(negf_ctx* c, int nb, int* info)
+{
+    ProfScope ps(c, "inverse");
+    int algo = c->inverse_algo;
+    if (algo == 0) algo = inverse_blocked_supported(c->n) ? 2 : 1;
+    if (algo == 2 && !inverse_blocked_supported(c->n)) algo = 1;
+    if (algo == 2) launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_ipiv, info);
+    else launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info);
+}
+
+// Sigma blocks of a block provider for energies E[0..nb) -> c->d_blk
+int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* iters, int* conv)
+{
+    if (p->kind == SK_CHAIN1D) {
+        ProfScope ps(c, "chain1d");
+        const size_t per = chain1d_scratch_per_wg(p->nc_max);
+        const size_t need = per * p->n_contacts * nb;
+        if (need > c->scratch_cap) {
+            NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+            dev_free(c->d_scratch); c->scratch_cap = 0;
+            int rc = dev_alloc(&c->d_scratch, need);
+            if (rc) return rc;
+            c->scratch_cap = need;
+        }
+        launch_chain1d(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, per);
+    } else if (p->kind == SK_BETHE) {
+        ProfScope ps(c, "bethe");
+        launch_bethe(c->stream, *p, nb, E, c->d_blk, iters, conv);
+    }
+    return NEGF_OK;
+}
+
+// assemble A_b = E_b S - F - Sigma_b for batch [m0, m0+nb) into c->d_A
+int run_assemble(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cplx* E)
+{
+    int rc = NEGF_OK;
+    if (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) {
+        rc = run_sigma_blocks(c, p, nb, E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
+                              c->d_conv + (size_t)m0 * p->n_contacts);
+        if (rc) return rc;
+    }
+    ProfScope ps(c, "assemble");
+    const size_t n2 = (size_t)c->n * c->n;
+    switch (p->kind) {
+    case SK_CONST:
+        launch_assemble(c->stream, c->n, nb, E + m0, c->d_S, p->d_hbase, nullptr, nullptr, 0, 0,
+                        nullptr, nullptr, nullptr, nullptr, c->d_A);
+        break;
+    case SK_PRECOMPUTED:
+        launch_assemble(c->stream, c->n, nb, E + m0, c->d_S, c->d_F, p->d_pre_tot + n2 * m0, nullptr, 0,
+                        0, nullptr, nullptr, nullptr, nullptr, c->d_A);
+        break;
+    case SK_CHAIN1D:
+    case SK_BETHE:
+        if (p->d_xi) {
+            // Sigma = Xi blockdiag Xi (surfGBethe.py:530-533): dense via two products
+            launch_scatter_blocks(c->stream, c->n, nb, c->d_blk, p->blk_stride, p->n_contacts, p->d_nc,
+                                  p->d_blk_off, p->d_inds_off, p->d_inds, -1, c->d_T1);
+            launch_zgemm(c->stream, c->n, c->n, c->n, nb, p->d_xi, c->n, 0, c->d_T1, c->n, n2, 0,
+                         c->d_T2, c->n, n2);
+            launch_zgemm(c->stream, c->n, c->n, c->n, nb, c->d_T2, c->n, n2, p->d_xi, c->n, 0, 0,
+                         c->d_T1, c->n, n2);
+            launch_assemble(c->stream, c->n, nb, E + m0, c->d_S, c->d_F, c->d_T1, nullptr, 0, 0, nullptr,
+                            nullptr, nullptr, nullptr, c->d_A);
+        } else {
+            launch_assemble(c->stream, c->n, nb, E + m0, c->d_S, c->d_F, nullptr, c->d_blk, p->blk_stride,
+                            p->n_contacts, p->d_nc, p->d_blk_off, p->d_inds_off, p->d_inds, c->d_A);
+        }
+        break;
+    default:
+        return NEGF_EINVAL;
+    }
+    return NEGF_OK;
+}
+
+// dense Gamma_b = i (Sigma_c - Sigma_c^H) for batch [m0, m0+nb) into `out`
+// (stride n*n); returns the batch stride to use (0 when one matrix serves all).
+int run_gamma(negf_ctx* c, SigmaProvider* p, int contact /* -1 total */, int m0, int nb, cplx* out,
+              const cplx** gptr, size_t* stride_out)
+{
+    const size_t n2 = (size_t)c->n * c->n;
+    *gptr = out;
+    if (p->kind == SK_PRECOMPUTED && p->pre_is_gamma) {
+        // the caller supplied the coupling matrices themselves (transport.py:150-181 take
+        // gamma1/gamma2 as arguments): use them in place
+        if (contact < 0 || !p->d_pre_c) return NEGF_EINVAL;
+        *gptr = p->d_pre_c + n2 * ((size_t)m0 * p->pre_nc + contact);
+        *stride_out = n2 * p->pre_nc;
+        return NEGF_OK;
+    }
+    switch (p->kind) {
+    case SK_CONST: {
+        const cplx* src = contact < 0 ? p->d_const_tot : p->d_const_c + n2 * contact;
+        launch_gamma_dense(c->stream, c->n, 1, src, 0, out);
+        *stride_out = 0;
+        return NEGF_OK;
+    }
+    case SK_PRECOMPUTED: {
+        if (contact < 0 || !p->d_pre_c) {
+            launch_gamma_dense(c->stream, c->n, nb, p->d_pre_tot + n2 * m0, n2, out);
+        } else {
+            const int pn = std::max(p->pre_nc, 1);
+            launch_gamma_dense(c->stream, c->n, nb, p->d_pre_c + n2 * ((size_t)m0 * pn + contact),
+                               n2 * pn, out);
+        }
+        *stride_out = n2;
+        return NEGF_OK;
+    }
+    case SK_CHAIN1D:
+    case SK_BETHE: {
+        // c->d_blk holds the blocks of this batch (run_assemble was just called)
+        launch_scatter_blocks(c->stream, c->n, nb, c->d_blk, p->blk_stride, p->n_contacts, p->d_nc,
+                              p->d_blk_off, p->d_inds_off, p->d_inds, contact, out);
+        if (p->d_xi) {
+            // Xi sig Xi through T2 as scratch; caller passes out != T2
+            launch_zgemm(c->stream, c->n, c->n, c->n, nb, p->d_xi, c->n, 0, out, c->n, n2, 0, c->d_T2,
+                         c->n, n2);
+            launch_zgemm(c->stream, c->n, c->n, c->n, nb, c->d_T2, c->n, n2, p->d_xi, c->n, 0, 0, out,
+                         c->n, n2);
+        }
+        // in place: gamma kernel reads s[t] and s[transpose]; use T2 as the target then copy back
+        launch_gamma_dense(c->stream, c->n, nb, out, n2, c->d_T2);
+        (void)hipMemcpyAsync(out, c->d_T2, n2 * nb * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream);
+        *stride_out = n2;
+        return NEGF_OK;
+    }
+    }
+    return NEGF_EINVAL;
+}
+
+int check_ready(negf_ctx* c, SigmaProvider* p, int m)
+{
+    if (!c || c->n <= 0) return NEGF_ESTATE;
+    if (!p) return NEGF_EINVAL;
+    if (m < 0) return NEGF_EINVAL;
+    if (p->kind == SK_PRECOMPUTED && m > p->m_pre) return NEGF_EINVAL;
+    return NEGF_OK;
+}
+
+int reduce_info(negf_ctx* c, int m, int* info_host)
+{
+    if (m == 0) return NEGF_OK;
+    std::vector<int> tmp;
+    int* dst = info_host;
+    if (!dst) { tmp.resize(m); dst = tmp.data(); }
+    int rc = download(c, dst, c->d_info, (size_t)m);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) if (dst[i] != 0) return NEGF_ESINGULAR;
+    return NEGF_OK;
+}
+
+}  // namespace
+
+// =========================================================================== //
+extern "C" {
+
+int negf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+const char* negf_version(void) { return "gaunegf_amd-0.1 (gfx950)"; }
+
+const char* negf_strerror(int code)
+{
+    switch (code) {
+    case NEGF_OK: return "ok";
+    case NEGF_EINVAL: return "invalid argument";
+    case NEGF_ENOMEM: return "out of device memory";
+    case NEGF_EHIP: return "HIP runtime error";
+    case NEGF_ENODEV: return "no HIP device available (this library has no CPU fallback)";
+    case NEGF_ESTATE: return "call negf_set_system first";
+    case NEGF_ESINGULAR: return "exactly singular matrix at one or more energies (see info[])";
+    default: return "unknown error";
+    }
+}
+
+int negf_create(negf_ctx** out, int device)
+{
+    if (!out) return NEGF_EINVAL;
+    *out = nullptr;
+    const int nd = negf_device_count();
+    if (nd <= 0) return NEGF_ENODEV;
+    if (device < 0 || device >= nd) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(device));
+    negf_ctx* c = new (std::nothrow) negf_ctx();
+    if (!c) return NEGF_ENOMEM;
+    c->device = device;
+    *out = c;
+    return NEGF_OK;
+}
+
+void negf_destroy(negf_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto* p : c->providers) free_provider(p);
+    free_workspace(c); free_mbuffers(c);
+    dev_free(c->d_F); dev_free(c->d_S); dev_free(c->d_acc);
+    prof_resolve(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int negf_set_stream(negf_ctx* c, void* s)
+{
+    if (!c) return NEGF_EINVAL;
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return NEGF_OK;
+}
+
+int negf_set_batch(negf_ctx* c, int batch)
+{
+    if (!c || batch < 0) return NEGF_EINVAL;
+    c->batch_user = batch;
+    return NEGF_OK;
+}
+int negf_get_batch(negf_ctx* c) { return c ? c->batch : 0; }
+
+int negf_set_inverse_algo(negf_ctx* c, int algo)
+{
+    if (!c || algo < 0 || algo > 2) return NEGF_EINVAL;
+    c->inverse_algo = algo;
+    return NEGF_OK;
+}
+
+int negf_set_system(negf_ctx* c, int n, const double* F, const double* S)
+{
+    if (!c || n <= 0 || !F || !S) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (n != c->n) {
+        // providers are tied to the matrix dimension
+        for (auto*& p : c->providers) { free_provider(p); p = nullptr; }
+        free_workspace(c);
+        dev_free(c->d_F); dev_free(c->d_S); dev_free(c->d_acc);
+        c->n = n;
+        const size_t n2 = (size_t)n * n;
+        int rc;
+        if ((rc = dev_alloc(&c->d_F, n2))) return rc;
+        if ((rc = dev_alloc(&c->d_S, n2))) return rc;
+        if ((rc = dev_alloc(&c->d_acc, n2))) return rc;
+    }
+    const size_t n2 = (size_t)n * n;
+    int rc;
+    if ((rc = upload(c, c->d_F, reinterpret_cast<const cplx*>(F), n2))) return rc;
+    if ((rc = upload(c, c->d_S, reinterpret_cast<const cplx*>(S), n2))) return rc;
+    // constant providers cache F + Sigma_tot: refresh them for the new F
+    for (auto* p : c->providers) {
+        if (p && p->kind == SK_CONST) {
+            std::vector<cplx> h(n2), st(n2);
+            if ((rc = download(c, st.data(), p->d_const_tot, n2))) return rc;
+            const cplx* Fh = reinterpret_cast<const cplx*>(F);
+            for (size_t i = 0; i < n2; ++i) h[i] = cadd(Fh[i], st[i]);
+            if ((rc = upload(c, p->d_hbase, h.data(), n2))) return rc;
+        }
+    }
+    return NEGF_OK;
+}
+
+// ------------------------------------------------------------------ providers
+int negf_sigma_const(negf_ctx* c, int n_contacts, const double* sigma, int* handle)
+{
+    if (!c || c->n <= 0) return NEGF_ESTATE;
+    if (n_contacts <= 0 || !sigma || !handle) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    SigmaProvider* p = new SigmaProvider();
+    p->kind = SK_CONST; p->n_contacts = n_contacts;
+    int rc;
+    if ((rc = dev_alloc(&p->d_const_c, n2 * n_contacts)) || (rc = dev_alloc(&p->d_const_tot, n2)) ||
+        (rc = dev_alloc(&p->d_hbase, n2))) { free_provider(p); return rc; }
+    const cplx* s = reinterpret_cast<const cplx*>(sigma);
+    // total = sum over contacts in contact order (surfGTester.py:128-131); F + total
+    // is a host-side O(n^2) setup step, the per-energy work stays on the GPU
+    std::vector<cplx> tot(n2, cmake(0.0, 0.0)), hb(n2), Fh(n2);
+    for (int k = 0; k < n_contacts; ++k)
+        for (size_t i = 0; i < n2; ++i) tot[i] = cadd(tot[i], s[k * n2 + i]);
+    if ((rc = download(c, Fh.data(), c->d_F, n2))) { free_provider(p); return rc; }
+    for (size_t i = 0; i < n2; ++i) hb[i] = cadd(Fh[i], tot[i]);
+    if ((rc = upload(c, p->d_const_c, s, n2 * n_contacts)) || (rc = upload(c, p->d_const_tot, tot.data(), n2)) ||
+        (rc = upload(c, p->d_hbase, hb.data(), n2))) { free_provider(p); return rc; }
+    *handle = add_provider(c, p);
+    return NEGF_OK;
+}
+
+static int setup_blocks(negf_ctx* c, SigmaProvider* p, int n_contacts, const int* nc, const int* inds)
+{
+    p->n_contacts = n_contacts;
+    p->nc.assign(nc, nc + n_contacts);
+    p->blk_off.resize(n_contacts); p->inds_off.resize(n_contacts);
+    int off = 0, ioff = 0;
+    p->nc_max = 0;
+    for (int k = 0; k < n_contacts; ++k) {
+        if (nc[k] <= 0 || nc[k] > c->n) return NEGF_EINVAL;
+        p->blk_off[k] = off; p->inds_off[k] = ioff;
+        off += nc[k] * nc[k]; ioff += nc[k];
+        p->nc_max = std::max(p->nc_max, nc[k]);
+    }
+    p->blk_stride = off;
+    p->h_inds.assign(inds, inds + ioff);
+    for (int v : p->h_inds) if (v < 0 || v >= c->n) return NEGF_EINVAL;
+    int rc;
+    if ((rc = dev_alloc(&p->d_inds, (size_t)ioff)) || (rc = dev_alloc(&p->d_nc, (size_t)n_contacts)) ||
+        (rc = dev_alloc(&p->d_blk_off, (size_t)n_contacts)) || (rc = dev_alloc(&p->d_inds_off, (size_t)n_contacts)))
+        return rc;
+    if ((rc = upload(c, p->d_inds, p->h_inds.data(), (size_t)ioff)) ||
+        (rc = upload(c, p->d_nc, p->nc.data(), (size_t)n_contacts)) ||
+        (rc = upload(c, p->d_blk_off, p->blk_off.data(), (size_t)n_contacts)) ||
+        (rc = upload(c, p->d_inds_off, p->inds_off.data(), (size_t)n_contacts)))
+        return rc;
+    return NEGF_OK;
+}
+
+int negf_sigma_chain1d(negf_ctx* c, int n_contacts, const int* nc, const int* inds,
+                       const double* alpha, const double* Salpha, const double* beta,
+                       const double* Sbeta, const double* tau, const double* Stau,
+                       double eta, double conv, double relFactor, int max_iter, int force_iters,
+                       int* handle)
+{
+    if (!c || c->n <= 0) return NEGF_ESTATE;
+    if (n_contacts <= 0 || !nc || !inds || !alpha || !Salpha || !beta || !Sbeta || !tau || !Stau || !handle)
+        return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    SigmaProvider* p = new SigmaProvider();
+    p->kind = SK_CHAIN1D;
+    int rc = setup_blocks(c, p, n_contacts, nc, inds);
+    if (rc) { free_provider(p); return rc; }
+    const size_t tot = (size_t)p->blk_stride;
+    cplx** dsts[6] = {&p->d_alpha, &p->d_Salpha, &p->d_beta, &p->d_Sbeta, &p->d_tau, &p->d_Stau};
+    const double* srcs[6] = {alpha, Salpha, beta, Sbeta, tau, Stau};
+    for (int k = 0; k < 6; ++k) {
+        if ((rc = dev_alloc(dsts[k], tot)) ||
+            (rc = upload(c, *dsts[k], reinterpret_cast<const cplx*>(srcs[k]), tot))) { free_provider(p); return rc; }
+    }
+    p->eta = eta; p->conv = conv; p->relFactor = relFactor; p->max_iter = max_iter;
+    p->force_iters = force_iters;
+    *handle = add_provider(c, p);
+    return NEGF_OK;
+}
+
+int negf_sigma_bethe(negf_ctx* c, int n_contacts, const int* n_atoms, const int* atom_orbs,
+                     const int* n_nb, const int* nb_dirs, const double* H, const double* Slist,
+                     const double* Vlist, const double* xi, double eta, double conv, double mix,
+                     int max_iter, int force_iters, int* handle)
+{
+    if (!c || c->n <= 0) return NEGF_ESTATE;
+    if (n_contacts <= 0 || !n_atoms || !atom_orbs || !n_nb || !H || !Slist || !Vlist || !handle)
+        return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    SigmaProvider* p = new SigmaProvider();
+    p->kind = SK_BETHE;
+    std::vector<int> nc(n_contacts);
+    int total_atoms = 0;
+    p->n_atoms.assign(n_atoms, n_atoms + n_contacts);
+    p->atom_off.resize(n_contacts);
+    for (int k = 0; k < n_contacts; ++k) {
+        if (n_atoms[k] <= 0) { free_provider(p); return NEGF_EINVAL; }
+        p->atom_off[k] = total_atoms;
+        nc[k] = 9 * n_atoms[k];
+        total_atoms += n_atoms[k];
+    }
+    int rc = setup_blocks(c, p, n_contacts, nc.data(), atom_orbs);
+    if (rc) { free_provider(p); return rc; }
+    std::vector<int> nb_off(total_atoms + 1, 0);
+    for (int a = 0; a < total_atoms; ++a) {
+        if (n_nb[a] < 0) { free_provider(p); return NEGF_EINVAL; }
+        nb_off[a + 1] = nb_off[a] + n_nb[a];
+    }
+    const int total_nb = nb_off[total_atoms];
+    if (total_nb > 0 && !nb_dirs) { free_provider(p); return NEGF_EINVAL; }
+    if ((rc = dev_alloc(&p->d_n_atoms, (size_t)n_contacts)) || (rc = dev_alloc(&p->d_atom_off, (size_t)n_contacts)) ||
+        (rc = dev_alloc(&p->d_nb_off, (size_t)total_atoms + 1)) || (rc = dev_alloc(&p->d_nb_dirs, (size_t)std::max(total_nb, 1))) ||
+        (rc = dev_alloc(&p->d_H, (size_t)n_contacts * 81)) || (rc = dev_alloc(&p->d_Slist, (size_t)n_contacts * 12 * 81)) ||
+        (rc = dev_alloc(&p->d_Vlist, (size_t)n_contacts * 12 * 81))) { free_provider(p); return rc; }
+    if ((rc = upload(c, p->d_n_atoms, p->n_atoms.data(), (size_t)n_contacts)) ||
+        (rc = upload(c, p->d_atom_off, p->atom_off.data(), (size_t)n_contacts)) ||
+        (rc = upload(c, p->d_nb_off, nb_off.data(), (size_t)total_atoms + 1)) ||
+        (rc = upload(c, p->d_nb_dirs, nb_dirs, (size_t)total_nb)) ||
+        (rc = upload(c, p->d_H, H, (size_t)n_contacts * 81)) ||
+        (rc = upload(c, p->d_Slist, Slist, (size_t)n_contacts * 12 * 81)) ||
+        (rc = upload(c, p->d_Vlist, Vlist, (size_t)n_contacts * 12 * 81))) { free_provider(p); return rc; }
+    if (xi) {
+        const size_t n2 = (size_t)c->n * c->n;
+        if ((rc = dev_alloc(&p->d_xi, n2)) ||
+            (rc = upload(c, p->d_xi, reinterpret_cast<const cplx*>(xi), n2))) { free_provider(p); return rc; }
+    }
+    p->eta = eta; p->conv = conv; p->mix = mix; p->max_iter = max_iter; p->force_iters = force_iters;
+    *handle = add_provider(c, p);
+    return NEGF_OK;
+}
+
+int negf_sigma_precomputed(negf_ctx* c, int m, const double* sigma_tot, int n_contacts_c,
+                           const double* sigma_c, int* handle)
+{
+    if (!c || c->n <= 0) return NEGF_ESTATE;
+    if (m <= 0 || !sigma_tot || !handle) return NEGF_EINVAL;
+    const bool is_gamma = n_contacts_c < 0;
+    if (is_gamma) { n_contacts_c = -n_contacts_c; if (!sigma_c) return NEGF_EINVAL; }
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    SigmaProvider* p = new SigmaProvider();
+    p->kind = SK_PRECOMPUTED; p->m_pre = m; p->n_contacts = std::max(n_contacts_c, 1);
+    p->pre_nc = sigma_c ? std::max(n_contacts_c, 1) : 0;
+    p->pre_is_gamma = is_gamma;
+    int rc;
+    if ((rc = dev_alloc(&p->d_pre_tot, n2 * m)) ||
+        (rc = upload(c, p->d_pre_tot, reinterpret_cast<const cplx*>(sigma_tot), n2 * m))) { free_provider(p); return rc; }
+    if (sigma_c) {
+        const size_t cnt = n2 * m * p->pre_nc;
+        if ((rc = dev_alloc(&p->d_pre_c, cnt)) ||
+            (rc = upload(c, p->d_pre_c, reinterpret_cast<const cplx*>(sigma_c), cnt))) { free_provider(p); return rc; }
+    }
+    *handle = add_provider(c, p);
+    return NEGF_OK;
+}
+
+int negf_sigma_free(negf_ctx* c, int handle)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    if (!p) return NEGF_EINVAL;
+    (void)hipStreamSynchronize(c->stream);
+    free_provider(p);
+    c->providers[handle] = nullptr;
+    return NEGF_OK;
+}
+
+// ------------------------------------------------------------- device variants
+int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const double* w_dev,
+                    double* out_dev)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out_dev || (m > 0 && (!E_dev || !w_dev))) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
+    if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
+    const cplx* E = reinterpret_cast<const cplx*>(E_dev);
+    const cplx* w = reinterpret_cast<const cplx*>(w_dev);
+    cplx* out = reinterpret_cast<cplx*>(out_dev);
+    NEGF_HIP_CHECK(hipMemsetAsync(out, 0, n2 * sizeof(cplx), c->stream));
+    for (int m0 = 0; m0 < m; m0 += c->batch) {
+        const int nb = std::min(c->batch, m - m0);
+        if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
+        run_inverse(c, nb, c->d_info + m0);
+        ProfScope ps(c, "accumulate");
+        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->d_A, out);
+    }
+    c->last_m = m;
+    NEGF_HIP_CHECK(hipGetLastError());
+    return NEGF_OK;
+}
+
+int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_dev,
+                       const double* w_dev, double* out_dev)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out_dev || (m > 0 && (!E_dev || !w_dev))) return NEGF_EINVAL;
+    const int contact = norm_contact(p, ind);
+    if (contact == -2) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    const int n = c->n;
+    if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
+    if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
+    const cplx* E = reinterpret_cast<const cplx*>(E_dev);
+    const cplx* w = reinterpret_cast<const cplx*>(w_dev);
+    cplx* out = reinterpret_cast<cplx*>(out_dev);
+    NEGF_HIP_CHECK(hipMemsetAsync(out, 0, n2 * sizeof(cplx), c->stream));
+    for (int m0 = 0; m0 < m; m0 += c->batch) {
+        const int nb = std::min(c->batch, m - m0);
+        if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
+        run_inverse(c, nb, c->d_info + m0);
+        size_t gs = 0;
+        const cplx* gam = nullptr;
+        { ProfScope ps(c, "gamma"); if ((rc = run_gamma(c, p, contact, m0, nb, c->d_T1, &gam, &gs))) return rc; }
+        {
+            ProfScope ps(c, "zgemm");
+            // T2 = G Gamma ; T1 = T2 G^H   (integrate.py:81)
+            launch_zgemm(c->stream, n, n, n, nb, c->d_A, n, n2, gam, n, gs, 0, c->d_T2, n, n2);
+            launch_zgemm(c->stream, n, n, n, nb, c->d_T2, n, n2, c->d_A, n, n2, 1, c->d_T1, n, n2);
+        }
+        ProfScope ps(c, "accumulate");
+        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->d_T1, out);
+    }
+    c->last_m = m;
+    NEGF_HIP_CHECK(hipGetLastError());
+    return NEGF_OK;
+}
+
+int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R, int spin_mode,
+                          int m, const double* E_dev, double* T_dev, double* Tspin_dev)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!T_dev || (m > 0 && !E_dev)) return NEGF_EINVAL;
+    if (spin_mode != NEGF_SPIN_RESTRICTED && spin_mode != NEGF_SPIN_BLOCK) return NEGF_EINVAL;
+    if (spin_mode == NEGF_SPIN_BLOCK && (!Tspin_dev || (c->n & 1))) return NEGF_EINVAL;
+    const int cL = norm_contact(p, contact_L), cR = norm_contact(p, contact_R);
+    if (cL == -2 || cR == -2) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const int n = c->n;
+    const size_t n2 = (size_t)n * n;
+    if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
+    // two extra n x n work areas per energy for Gamma_L / Gamma_R: reuse T1/T2 for
+    // the Gammas and carve the product temporaries out of a second workspace half
+    if ((rc = ensure_workspace(c, 2 * std::max(m, 1), p->blk_stride, 2))) return rc;
+    const cplx* E = reinterpret_cast<const cplx*>(E_dev);
+    // process with half the allocated batch so that [0,half) holds this sweep's
+    // matrices and [half, 2*half) is free scratch in each of A/T1/T2
+    const int half = std::max(1, c->batch / 2);
+    for (int m0 = 0; m0 < m; m0 += half) {
+        const int nb = std::min(half, m - m0);
+        if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
+        run_inverse(c, nb, c->d_info + m0);
+        cplx* G = c->d_A;
+        const cplx* gamL = nullptr;           // [nb] (or one shared matrix)
+        const cplx* gamR = nullptr;
+        cplx* X = c->d_T2;                    // [nb]
+        cplx* Y = c->d_A + n2 * half;         // [nb]
+        size_t gsL = 0, gsR = 0;
+        {
+            ProfScope ps(c, "gamma");
+            // run_gamma uses T2 as scratch for block providers -> build both before X is live
+            if ((rc = run_gamma(c, p, cL, m0, nb, c->d_T1, &gamL, &gsL))) return rc;
+            if ((rc = run_gamma(c, p, cR, m0, nb, c->d_T1 + n2 * half, &gamR, &gsR))) return rc;
+        }
+        if (spin_mode == NEGF_SPIN_RESTRICTED) {
+            {
+                ProfScope ps(c, "zgemm");
+                // X = Gamma_L G ; Y = X Gamma_R ; T = Re sum Y_ij conj(G_ij)  (transport.py:156-157)
+                launch_zgemm(c->stream, n, n, n, nb, gamL, n, gsL, G, n, n2, 0, X, n, n2);
+                launch_zgemm(c->stream, n, n, n, nb, X, n, n2, gamR, n, gsR, 0, Y, n, n2);
+            }
+            ProfScope ps(c, "trace");
+            launch_trace_dot(c->stream, n, n, nb, Y, n, n2, G, n, n2, T_dev + m0, 1);
+        } else {
+            const int h = n / 2;
+            // blocks [uu, ud, du, dd]: G rows/cols offsets; Gamma_L blocks [uu,uu,dd,dd];
+            // Gamma_R blocks [uu,dd,uu,dd]; Ga_k = (G^H)[R,C] = conj(G[C,R])^T  (transport.py:166-177)
+            const int gr[4] = {0, 0, h, h}, gc[4] = {0, h, 0, h};
+            const int l_off[4] = {0, 0, h, h}, r_off[4] = {0, h, 0, h};
+            for (int k = 0; k < 4; ++k) {
+                const cplx* Gk = G + (size_t)gr[k] * n + gc[k];
+                const cplx* GLk = gamL + (size_t)l_off[k] * n + l_off[k];
+                const cplx* GRk = gamR + (size_t)r_off[k] * n + r_off[k];
+                // trace pairs X_k[i][j] with conj(G[C0+i][R0+j])
+                const cplx* Gpair = G + (size_t)gc[k] * n + gr[k];
+                {
+                    ProfScope ps(c, "zgemm");
+                    launch_zgemm(c->stream, h, h, h, nb, GLk, n, gsL, Gk, n, n2, 0, X, h, n2);
+                    launch_zgemm(c->stream, h, h, h, nb, X, h, n2, GRk, n, gsR, 0, Y, h, n2);
+                }
+                ProfScope ps(c, "trace");
+                launch_trace_dot(c->stream, h, h, nb, Y, h, n2, Gpair, n, n2, Tspin_dev + (size_t)m0 * 4 + k, 4);
+            }
+        }
+    }
+    c->last_m = m;
+    NEGF_HIP_CHECK(hipGetLastError());
+    return NEGF_OK;
+}
+
+int negf_sync(negf_ctx* c)
+{
+    if (!c) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return NEGF_OK;
+}
+
+int negf_last_info(negf_ctx* c, int m, int* info)
+{
+    if (!c || !info || m < 0 || m > c->m_cap) return NEGF_EINVAL;
+    return download(c, info, c->d_info, (size_t)m);
+}
+
+// --------------------------------------------------------------- host variants
+static int stage_grid(negf_ctx* c, int m, int contacts, const double* E, const double* w)
+{
+    int rc = ensure_mbuffers(c, m, contacts);
+    if (rc) return rc;
+    if (E && (rc = upload(c, c->d_E, reinterpret_cast<const cplx*>(E), (size_t)m))) return rc;
+    if (w && (rc = upload(c, c->d_w, reinterpret_cast<const cplx*>(w), (size_t)m))) return rc;
+    return NEGF_OK;
+}
+
+int negf_gr_int(negf_ctx* c, int handle, int m, const double* E, const double* w, double* out,
+                int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out || (m > 0 && (!E || !w))) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
+    if ((rc = negf_gr_int_dev(c, handle, m, reinterpret_cast<double*>(c->d_E),
+                              reinterpret_cast<double*>(c->d_w), reinterpret_cast<double*>(c->d_acc)))) return rc;
+    if ((rc = download(c, reinterpret_cast<cplx*>(out), c->d_acc, (size_t)c->n * c->n))) return rc;
+    return reduce_info(c, m, info);
+}
+
+int negf_gless_int(negf_ctx* c, int handle, int ind, int m, const double* E, const double* w,
+                   double* out, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out || (m > 0 && (!E || !w))) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
+    if ((rc = negf_gless_int_dev(c, handle, ind, m, reinterpret_cast<double*>(c->d_E),
+                                 reinterpret_cast<double*>(c->d_w), reinterpret_cast<double*>(c->d_acc)))) return rc;
+    if ((rc = download(c, reinterpret_cast<cplx*>(out), c->d_acc, (size_t)c->n * c->n))) return rc;
+    return reduce_info(c, m, info);
+}
+
+int negf_gr_batch(negf_ctx* c, int handle, int m, const double* E, double* G_out, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (m > 0 && (!E || !G_out)) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    if ((rc = stage_grid(c, m, p->n_contacts, E, nullptr))) return rc;
+    if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
+    for (int m0 = 0; m0 < m; m0 += c->batch) {
+        const int nb = std::min(c->batch, m - m0);
+        if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
+        run_inverse(c, nb, c->d_info + m0);
+        if ((rc = download(c, reinterpret_cast<cplx*>(G_out) + n2 * m0, c->d_A, n2 * nb))) return rc;
+    }
+    c->last_m = m;
+    return reduce_info(c, m, info);
+}
+
+int negf_transmission(negf_ctx* c, int handle, int contact_L, int contact_R, int spin_mode, int m,
+                      const double* E, double* T, double* Tspin, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (m > 0 && (!E || !T)) return NEGF_EINVAL;
+    if (spin_mode == NEGF_SPIN_BLOCK && !Tspin) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    if ((rc = stage_grid(c, m, p->n_contacts, E, nullptr))) return rc;
+    double* dT = c->d_scal;                 // [m]
+    double* dTs = c->d_scal + c->m_cap;     // [m][4]
+    if ((rc = negf_transmission_dev(c, handle, contact_L, contact_R, spin_mode, m,
+                                    reinterpret_cast<double*>(c->d_E), dT, dTs))) return rc;
+    if (spin_mode == NEGF_SPIN_BLOCK) {
+        if ((rc = download(c, Tspin, dTs, (size_t)m * 4))) return rc;
+        for (int i = 0; i < m; ++i) {
+            // total = sum of the four components in order, as jnp.sum(T_spin) (transport.py:181)
+            T[i] = ((Tspin[4 * i] + Tspin[4 * i + 1]) + Tspin[4 * i + 2]) + Tspin[4 * i + 3];
+        }
+    } else {
+        if ((rc = download(c, T, dT, (size_t)m))) return rc;
+    }
+    return reduce_info(c, m, info);
+}
+
+int negf_dos(negf_ctx* c, int handle, int m, const double* E, double* dos_total, double* dos_site,
+             int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (m > 0 && (!E || !dos_total)) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    if ((rc = stage_grid(c, m, p->n_contacts, E, nullptr))) return rc;
+    if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
+    for (int m0 = 0; m0 < m; m0 += c->batch) {
+        const int nb = std::min(c->batch, m - m0);
+        if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
+        run_inverse(c, nb, c->d_info + m0);
+        { ProfScope ps(c, "trace"); launch_dos(c->stream, c->n, nb, c->d_A, c->d_scal + m0, dos_site ? c->d_site : nullptr); }
+        if (dos_site && (rc = download(c, dos_site + (size_t)m0 * c->n, c->d_site, (size_t)nb * c->n))) return rc;
+    }
+    if ((rc = download(c, dos_total, c->d_scal, (size_t)m))) return rc;
+    c->last_m = m;
+    return reduce_info(c, m, info);
+}
+
+int negf_sigma_eval(negf_ctx* c, int handle, int contact, int m, const double* E, double* sigma_out,
+                    int* iters, int* converged)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (m > 0 && (!E || !sigma_out)) return NEGF_EINVAL;
+    const int ct = norm_contact(p, contact);
+    if (ct == -2) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    if ((rc = stage_grid(c, m, p->n_contacts, E, nullptr))) return rc;
+    if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
+    cplx* out = reinterpret_cast<cplx*>(sigma_out);
+    for (int m0 = 0; m0 < m; m0 += c->batch) {
+        const int nb = std::min(c->batch, m - m0);
+        switch (p->kind) {
+        case SK_CONST: {
+            const cplx* src = ct < 0 ? p->d_const_tot : p->d_const_c + n2 * ct;
+            for (int b = 0; b < nb; ++b)
+                if ((rc = download(c, out + n2 * (m0 + b), src, n2))) return rc;
+            break;
+        }
+        case SK_PRECOMPUTED: {
+            const cplx* src = (ct < 0 || !p->d_pre_c) ? p->d_pre_tot + n2 * m0 : nullptr;
+            if (src) { if ((rc = download(c, out + n2 * m0, src, n2 * nb))) return rc; }
+            else {
+                const int pn = std::max(p->pre_nc, 1);
+                for (int b = 0; b < nb; ++b)
+                    if ((rc = download(c, out + n2 * (m0 + b), p->d_pre_c + n2 * ((size_t)(m0 + b) * pn + ct), n2))) return rc;
+            }
+            break;
+        }
+        case SK_CHAIN1D:
+        case SK_BETHE: {
+            if ((rc = run_sigma_blocks(c, p, nb, c->d_E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
+                                       c->d_conv + (size_t)m0 * p->n_contacts))) return rc;
+            launch_scatter_blocks(c->stream, c->n, nb, c->d_blk, p->blk_stride, p->n_contacts, p->d_nc,
+                                  p->d_blk_off, p->d_inds_off, p->d_inds, ct, c->d_A);
+            cplx* res = c->d_A;
+            if (p->d_xi) {
+                launch_zgemm(c->stream, c->n, c->n, c->n, nb, p->d_xi, c->n, 0, c->d_A, c->n, n2, 0, c->d_T2, c->n, n2);
+                launch_zgemm(c->stream, c->n, c->n, c->n, nb, c->d_T2, c->n, n2, p->d_xi, c->n, 0, 0, c->d_A, c->n, n2);
+            }
+            if ((rc = download(c, out + n2 * m0, res, n2 * nb))) return rc;
+            break;
+        }
+        default: return NEGF_EINVAL;
+        }
+    }
+    if (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) {
+        if (iters && (rc = download(c, iters, c->d_iters, (size_t)m * p->n_contacts))) return rc;
+        if (converged && (rc = download(c, converged, c->d_conv, (size_t)m * p->n_contacts))) return rc;
+    } else {
+        if (iters) for (int i = 0; i < m * p->n_contacts; ++i) iters[i] = 0;
+        if (converged) for (int i = 0; i < m * p->n_contacts; ++i) converged[i] = 1;
+    }
+    NEGF_HIP_CHECK(hipGetLastError());
+    return NEGF_OK;
+}
+
+int negf_bethe_raw(negf_ctx* c, const double* H, const double* Slist, const double* Vlist, double eta,
+                   double conv, double mix, int max_iter, int force_iters, int which, int m,
+                   const double* E, double* out, int* iters, int* converged)
+{
+    if (!c || !H || !Slist || !Vlist || m < 0 || (which != 1 && which != 2)) return NEGF_EINVAL;
+    if (m > 0 && (!E || !out)) return NEGF_EINVAL;
+    if (m == 0) return NEGF_OK;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const int nd = which == 1 ? 12 : 9;
+    double *dH = nullptr, *dS = nullptr, *dV = nullptr;
+    cplx *dE = nullptr, *dout = nullptr;
+    int *dit = nullptr, *dcv = nullptr;
+    int rc = NEGF_OK;
+    if ((rc = dev_alloc(&dH, 81)) || (rc = dev_alloc(&dS, 12 * 81)) || (rc = dev_alloc(&dV, 12 * 81)) ||
+        (rc = dev_alloc(&dE, (size_t)m)) || (rc = dev_alloc(&dout, (size_t)m * nd * 81)) ||
+        (rc = dev_alloc(&dit, (size_t)m)) || (rc = dev_alloc(&dcv, (size_t)m))) goto done;
+    if ((rc = upload(c, dH, H, 81)) || (rc = upload(c, dS, Slist, 12 * 81)) || (rc = upload(c, dV, Vlist, 12 * 81)) ||
+        (rc = upload(c, dE, reinterpret_cast<const cplx*>(E), (size_t)m))) goto done;
+    {
+        ProfScope ps(c, "bethe");
+        launch_bethe_raw(c->stream, dH, dS, dV, eta, conv, mix, max_iter, force_iters, which, m, dE, dout, dit, dcv);
+    }
+    if ((rc = download(c, reinterpret_cast<cplx*>(out), dout, (size_t)m * nd * 81))) goto done;
+    if (iters && (rc = download(c, iters, dit, (size_t)m))) goto done;
+    if (converged && (rc = download(c, converged, dcv, (size_t)m))) goto done;
+    if (hipGetLastError() != hipSuccess) rc = NEGF_EHIP;
+done:
+    dev_free(dH); dev_free(dS); dev_free(dV); dev_free(dE); dev_free(dout); dev_free(dit); dev_free(dcv);
+    return rc;
+}
+
+// ------------------------------------------------------------------ diagnostics
+int negf_profile_enable(negf_ctx* c, int on) { if (!c) return NEGF_EINVAL; c->profiling = on != 0; return NEGF_OK; }
+int negf_profile_reset(negf_ctx* c) { if (!c) return NEGF_EINVAL; prof_resolve(c); c->prof.clear(); return NEGF_OK; }
+int negf_profile_read(negf_ctx* c, const char* family, double* total_ms, int* launches)
+{
+    if (!c || !family) return NEGF_EINVAL;
+    prof_resolve(c);
+    auto it = c->prof.find(family);
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    return NEGF_OK;
+}
+
+int negf_selftest_mfma(negf_ctx* c, double* max_err)
+{
+    if (!c || !max_err) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    return run_mfma_selftest(c->stream, max_err);
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// Internal declarations shared by the translation units of libnegf_hip.so.
+// gfx950 (MI355X) only; wavefront = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/negf.h"
+
+// ------------------------------------------------------------------ complex
+// complex128 as an aligned pair: one 16-byte global/LDS access per element.
+struct __attribute__((aligned(16))) cplx {
+    double x, y;
+};
+static_assert(sizeof(cplx) == 16, "cplx must be 16 bytes");
+
+__host__ __device__ __forceinline__ cplx cmake(double a, double b) { cplx r; r.x = a; r.y = b; return r; }
+__host__ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__host__ __device__ __forceinline__ cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__host__ __device__ __forceinline__ cplx cneg(cplx a) { return cmake(-a.x, -a.y); }
+__host__ __device__ __forceinline__ cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+__host__ __device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a - b*c
+__host__ __device__ __forceinline__ cplx cfnma(cplx a, cplx b, cplx c) {
+    return cmake(a.x - b.x * c.x + b.y * c.y, a.y - b.x * c.y - b.y * c.x);
+}
+// a + b*c
+__host__ __device__ __forceinline__ cplx cfma(cplx a, cplx b, cplx c) {
+    return cmake(a.x + b.x * c.x - b.y * c.y, a.y + b.x * c.y + b.y * c.x);
+}
+__host__ __device__ __forceinline__ cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+// LAPACK izamax metric |re|+|im| (what zgetrf pivots on)
+__host__ __device__ __forceinline__ double cabs1(cplx a) { return fabs(a.x) + fabs(a.y); }
+__host__ __device__ __forceinline__ double cabs2(cplx a) { return a.x * a.x + a.y * a.y; }
+// 1/a with scaling against overflow/underflow (Smith)
+__host__ __device__ __forceinline__ cplx crecip(cplx a) {
+    if (fabs(a.x) >= fabs(a.y)) {
+        double r = a.y / a.x;
+        double d = a.x + a.y * r;
+        return cmake(1.0 / d, -r / d);
+    } else {
+        double r = a.x / a.y;
+        double d = a.x * r + a.y;
+        return cmake(r / d, -1.0 / d);
+    }
+}
+
+// -------------------------------------------------------------- error macros
+#define NEGF_HIP_CHECK(expr)                                                          \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            fprintf(stderr, "[negf] HIP error %s at %s:%d: %s\n", #expr, __FILE__,    \
+                    __LINE__, hipGetErrorString(_e));                                 \
+            return NEGF_EHIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+// ------------------------------------------------------------------- context
+enum SigmaKind { SK_CONST = 0, SK_CHAIN1D = 2, SK_BETHE = 3, SK_PRECOMPUTED = 4 };
+
+struct SigmaProvider {
+    int kind = -1;
+    int n_contacts = 0;
+    // CONST: dense per-contact Sigma [n_contacts][n][n] and their sum, on device
+    cplx* d_const_c = nullptr;     // [n_contacts][n*n]
+    cplx* d_const_tot = nullptr;   // [n*n]
+    cplx* d_hbase = nullptr;       // F + Sigma_tot (CONST only): A = E S - hbase
+    // block providers (CHAIN1D / BETHE): contact blocks scattered at inds x inds
+    std::vector<int> nc;           // block size per contact
+    std::vector<int> blk_off;      // offset (in cplx) of contact c inside one energy's block record
+    int blk_stride = 0;            // cplx per energy = sum nc^2
+    int nc_max = 0;
+    int* d_inds = nullptr;         // concatenated orbital indices
+    int *d_nc = nullptr, *d_blk_off = nullptr, *d_inds_off = nullptr;   // device copies
+    int *d_n_atoms = nullptr, *d_atom_off = nullptr;
+    std::vector<int> inds_off;     // offset of contact c in d_inds
+    std::vector<int> h_inds;
+    // CHAIN1D matrices, concatenated [sum nc^2] each
+    cplx *d_alpha = nullptr, *d_Salpha = nullptr, *d_beta = nullptr, *d_Sbeta = nullptr,
+         *d_tau = nullptr, *d_Stau = nullptr;
+    double eta = 0, conv = 0, relFactor = 0, mix = 0;
+    int max_iter = 0, force_iters = -1;
+    // BETHE
+    std::vector<int> n_atoms;      // atoms per contact
+    int* d_atom_orbs = nullptr;    // [total_atoms][9]
+    int* d_nb_off = nullptr;       // [total_atoms+1]
+    int* d_nb_dirs = nullptr;
+    std::vector<int> atom_off;     // first atom of contact c
+    double* d_H = nullptr;         // [n_contacts][81]
+    double* d_Slist = nullptr;     // [n_contacts][12][81]
+    double* d_Vlist = nullptr;
+    cplx* d_xi = nullptr;          // [n*n] or null
+    // PRECOMPUTED
+    int m_pre = 0;
+    int pre_nc = 0;
+    bool pre_is_gamma = false;     // d_pre_c holds the Gamma matrices themselves
+    cplx* d_pre_tot = nullptr;     // [m][n*n]
+    cplx* d_pre_c = nullptr;       // [m][pre_nc][n*n] or null
+};
+
+struct ProfEntry { double ms = 0; int launches = 0; };
+
+struct negf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n = 0;
+    cplx* d_F = nullptr;
+    cplx* d_S = nullptr;
+    int batch_user = 0;            // 0 = auto
+    int batch = 0;                 // allocated workspace batch
+    // workspace, sized for `batch` energies
+    cplx* d_A = nullptr;           // [batch][n*n]   assembled matrix -> inverse in place
+    cplx* d_T1 = nullptr;          // [batch][n*n]   temp products
+    cplx* d_T2 = nullptr;          // [batch][n*n]
+    cplx* d_blk = nullptr;         // [batch][blk_stride] contact blocks of Sigma(E)
+    int blk_cap = 0;
+    cplx* d_scratch = nullptr;     // per-workgroup scratch of the Sigma kernels
+    size_t scratch_cap = 0;
+    int* d_ipiv = nullptr;         // [batch][n]
+    int* d_info = nullptr;         // [m_cap]
+    int* d_iters = nullptr;        // [m_cap][contacts]
+    int* d_conv = nullptr;
+    int m_cap = 0;
+    int contacts_cap = 0;
+    cplx* d_E = nullptr;           // staging for host-pointer API
+    cplx* d_w = nullptr;
+    cplx* d_acc = nullptr;         // [n*n] result staging
+    double* d_scal = nullptr;      // [m_cap][8] scalar outputs
+    double* d_site = nullptr;      // [batch][n] per-site DOS staging
+    int inverse_algo = 0;
+    int last_m = 0;
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    struct Pending { std::string name; hipEvent_t e0, e1; };
+    std::vector<Pending> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<SigmaProvider*> providers;
+};
+
+// Profiling bracket used by the orchestration code: two hipEvents recorded on the
+// context's stream around a kernel family, WITHOUT any host synchronisation (the
+// timed region of bench.py runs with this enabled); elapsed times are resolved when
+// negf_profile_read is called.
+struct ProfScope {
+    negf_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(negf_ctx* ctx, const char* nm);
+    ~ProfScope();
+};
+
+// ------------------------------------------------------------ kernel launchers
+// (implemented in k_*.hip; all asynchronous on `st`)
+
+// A[b] = E[b]*S - H - (dense Sigma_b) - scatter(blocks_b)
+void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S, const cplx* H,
+                     const cplx* sig_dense /*[nb][n*n] or null*/,
+                     const cplx* blk /*[nb][blk_stride] or null*/, int blk_stride,
+                     int n_contacts, const int* d_nc /*device [n_contacts]*/,
+                     const int* d_blk_off, const int* d_inds_off, const int* d_inds,
+                     cplx* A);
+
+// in-place inverse of nb matrices; info[b] = 0 or 1-based column of a zero pivot
+void launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
+void launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, int* ipiv, int* info);
+bool inverse_blocked_supported(int n);
+
+// acc += sum_b w[b] * X[b]   (fixed order b = 0..nb-1, deterministic)
+void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc);
+
+// C[b] (M x N) = A[b] (M x K) * op(B[b]);  a batch stride of 0 broadcasts one matrix.
+// opB: 0 -> B is K x N (ldb >= N); 1 -> op(B) = B^H with B stored N x K (ldb >= K).
+void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
+                  const cplx* A, int lda, size_t strideA,
+                  const cplx* B, int ldb, size_t strideB, int opB,
+                  cplx* C, int ldc, size_t strideC);
+
+// out[b*out_stride] = Re sum_{i<nr, j<ncol} X[b][i*ldx+j] * conj(G[b][i*ldg+j])
+void launch_trace_dot(hipStream_t st, int nr, int ncol, int nb, const cplx* X, int ldx,
+                      size_t strideX, const cplx* G, int ldg, size_t strideG,
+                      double* out, int out_stride);
+
+// dos_site[b][i] = -Im G[b]_ii / pi ; dos_tot[b] = sum_i
+void launch_dos(hipStream_t st, int n, int nb, const cplx* G, double* dos_tot, double* dos_site);
+
+// Gamma = i (Sigma - Sigma^H) for nb dense matrices (stride 0 allowed on input)
+void launch_gamma_dense(hipStream_t st, int n, int nb, const cplx* sig, size_t stride_sig, cplx* gam);
+
+// dense Sigma from contact blocks: out[b] = scatter-add of selected contacts (contact<0: all)
+void launch_scatter_blocks(hipStream_t st, int n, int nb, const cplx* blk, int blk_stride,
+                           int n_contacts, const int* d_nc, const int* d_blk_off,
+                           const int* d_inds_off, const int* d_inds, int contact, cplx* out);
+
+// 1-D chain decimation: one workgroup per (energy, contact)
+void launch_chain1d(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off,
+                    int nb, const cplx* E, cplx* blk, int* iters, int* conv, cplx* scratch,
+                    size_t scratch_per_wg);
+size_t chain1d_scratch_per_wg(int nc_max);
+
+// Bethe lattice: one workgroup per (energy, contact); writes per-atom 9x9 blocks
+void launch_bethe(hipStream_t st, const SigmaProvider& p, int nb, const cplx* E, cplx* blk,
+                  int* iters, int* conv);
+
+void launch_bethe_raw(hipStream_t st, const double* d_H, const double* d_S, const double* d_V, double eta,
+                      double conv, double mix, int max_iter, int force_iters, int which, int nb,
+                      const cplx* E, cplx* out, int* iters, int* converged);
+
+int run_mfma_selftest(hipStream_t st, double* max_err);

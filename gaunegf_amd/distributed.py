@@ -1,0 +1,103 @@
+"""
+Energy-grid sharding across the GPUs of one node.
+
+The reference is single-process / single-device (no pmap, no collectives).  Here the
+energy points of one integral are independent units: rank r of W takes the points
+m = r, r+W, r+2W, ... (cyclic, which balances the data-dependent iteration counts
+of the self-energy fixed points and the stiffer points near the real axis), every
+rank accumulates its partial N x N sum on its own GPU, and ONE sum all-reduce of
+2 N^2 doubles (RCCL over xGMI; ``backend="nccl"`` is RCCL on ROCm) finishes the
+integral.  Per-energy scalars (T(E), DOS(E)) are combined the same way on a
+zero-filled length-M vector, which is exact (x + 0 == x).
+
+Opt-in: call ``enable()`` after ``torch.distributed.init_process_group``; every rank
+must then call GrInt / GrLessInt / calculate_transmission with the same arguments
+(SPMD).  Without ``enable()`` the drop-in functions stay purely local.
+"""
+import numpy as np
+
+_state = {"enabled": False, "group": None}
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def enable(group=None):
+    dist = _dist()
+    if not dist.is_available() or not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
+    _state["enabled"] = True
+    _state["group"] = group
+
+
+def disable():
+    _state["enabled"] = False
+    _state["group"] = None
+
+
+def is_active():
+    if not _state["enabled"]:
+        return False
+    dist = _dist()
+    return dist.is_initialized() and dist.get_world_size(_state["group"]) > 1
+
+
+def rank_world():
+    if not is_active():
+        return 0, 1
+    dist = _dist()
+    return dist.get_rank(_state["group"]), dist.get_world_size(_state["group"])
+
+
+def shard_indices(m, rank, world):
+    """Cyclic partition: indices of the energies owned by ``rank``."""
+    return np.arange(rank, m, world)
+
+
+def allreduce_sum(arr):
+    """Sum a numpy array over all ranks (float64 / complex128), result on every rank."""
+    import torch
+    dist = _dist()
+    a = np.ascontiguousarray(arr)
+    is_c = np.iscomplexobj(a)
+    flat = a.view(np.float64) if is_c else a.astype(np.float64, copy=False)
+    t = torch.from_numpy(flat.copy())
+    backend = dist.get_backend(_state["group"])
+    if backend == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
+    out = t.cpu().numpy()
+    return out.view(np.complex128).reshape(a.shape) if is_c else out.reshape(a.shape)
+
+
+def allreduce_sum_tensor(t):
+    """In-place sum all-reduce of a (device) tensor; the device-resident path of
+    bench.py and of large integrals: 2 N^2 doubles, one collective per integral."""
+    dist = _dist()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
+    return t
+
+
+def sharded_sum(partial_fn, m):
+    """``partial_fn(idx)`` returns the partial sum over energy indices ``idx``;
+    returns the full sum on every rank."""
+    if not is_active():
+        return partial_fn(slice(None))
+    rank, world = rank_world()
+    part = partial_fn(shard_indices(m, rank, world))
+    return allreduce_sum(part)
+
+
+def sharded_map(partial_fn, m, tail_shape=()):
+    """``partial_fn(idx)`` returns per-energy values [len(idx), *tail_shape]; returns
+    the full [m, *tail_shape] array on every rank."""
+    if not is_active():
+        return partial_fn(slice(None))
+    rank, world = rank_world()
+    idx = shard_indices(m, rank, world)
+    full = np.zeros((m,) + tuple(tail_shape), dtype=np.float64)
+    if idx.size:
+        full[idx] = partial_fn(idx)
+    return allreduce_sum(full)

@@ -1,0 +1,327 @@
+"""
+Engine: thin Python owner of one ``negf_ctx`` (one process, one GPU).
+
+All O(N^3) M work happens in libnegf_hip.so; this class only converts numpy
+arrays to the C ABI's layout (C-contiguous complex128) and keeps handles alive.
+PyTorch is not needed here; the *_dev methods accept raw device pointers
+(``tensor.data_ptr()``) so that a torch-managed buffer can be all-reduced with
+RCCL afterwards (distributed.py).
+"""
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import NEGF_IND_TOTAL, NEGF_SPIN_BLOCK, NEGF_SPIN_RESTRICTED, check
+
+_engines = {}
+
+
+def _c128(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a), dtype=np.complex128)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ind(ind):
+    return NEGF_IND_TOTAL if ind is None else int(ind)
+
+
+class Engine:
+    def __init__(self, device=None):
+        self._lib = _lib.load()
+        ndev = self._lib.negf_device_count()
+        if ndev <= 0:
+            raise RuntimeError(
+                "gaunegf_amd: no HIP device visible.  The NEGF engine is GPU-only "
+                "(hand-written gfx950 kernels); there is no CPU fallback.")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % ndev
+        self.device = int(device)
+        ctx = C.c_void_p()
+        check(self._lib.negf_create(C.byref(ctx), self.device), "negf_create")
+        self._ctx = ctx
+        self.n = 0
+        self._F = None
+        self._S = None
+        self.last_info = None
+        self.last_iters = None
+        self.last_converged = None
+
+    # ------------------------------------------------------------- lifetime
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.negf_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.negf_set_stream(self._ctx, C.c_void_p(stream_ptr or 0)), "negf_set_stream")
+
+    def set_batch(self, batch):
+        check(self._lib.negf_set_batch(self._ctx, int(batch)), "negf_set_batch")
+
+    def get_batch(self):
+        return self._lib.negf_get_batch(self._ctx)
+
+    def set_inverse_algo(self, algo):
+        check(self._lib.negf_set_inverse_algo(self._ctx, int(algo)), "negf_set_inverse_algo")
+
+    def sync(self):
+        check(self._lib.negf_sync(self._ctx), "negf_sync")
+
+    # --------------------------------------------------------------- system
+    def set_system(self, F, S):
+        """Upload F,S (skipped when identical to what is already resident)."""
+        F = _c128(F)
+        S = _c128(S)
+        assert F.shape == S.shape, "F and S must have the same shape"
+        assert F.ndim == 2 and F.shape[0] == F.shape[1], "F and S must be square matrices"
+        if (self._F is not None and self._F.shape == F.shape and
+                np.array_equal(self._F, F) and np.array_equal(self._S, S)):
+            return False
+        n_changed = F.shape[0] != self.n
+        check(self._lib.negf_set_system(self._ctx, F.shape[0], _ptr(F), _ptr(S)), "negf_set_system")
+        self.n = F.shape[0]
+        self._F = F.copy()
+        self._S = S.copy()
+        if n_changed:
+            self.generation = getattr(self, "generation", 0) + 1   # provider handles died
+        return True
+
+    # ------------------------------------------------------------ providers
+    def sigma_const(self, sigmas):
+        sig = _c128(np.stack([np.asarray(s) for s in sigmas]))
+        assert sig.shape[1:] == (self.n, self.n), "sigma shape must match F"
+        h = C.c_int(-1)
+        check(self._lib.negf_sigma_const(self._ctx, sig.shape[0], _ptr(sig), C.byref(h)), "negf_sigma_const")
+        return h.value
+
+    def sigma_chain1d(self, inds_list, alphas, Salphas, betas, Sbetas, taus, Staus,
+                      eta, conv, relFactor, max_iter=2000, force_iters=-1):
+        nc = np.array([len(i) for i in inds_list], dtype=np.int32)
+        inds = np.ascontiguousarray(np.concatenate([np.asarray(i).ravel() for i in inds_list]), dtype=np.int32)
+
+        def cat(mats):
+            out = []
+            for k, m in enumerate(mats):
+                m = _c128(m)
+                if m.shape != (nc[k], nc[k]):
+                    raise ValueError(f"contact {k}: expected {nc[k]}x{nc[k]} matrix, got {m.shape}")
+                out.append(m.ravel())
+            return np.ascontiguousarray(np.concatenate(out))
+        a, Sa, b, Sb, t, St = (cat(x) for x in (alphas, Salphas, betas, Sbetas, taus, Staus))
+        h = C.c_int(-1)
+        check(self._lib.negf_sigma_chain1d(self._ctx, len(nc), _ptr(nc), _ptr(inds), _ptr(a), _ptr(Sa),
+                                           _ptr(b), _ptr(Sb), _ptr(t), _ptr(St), float(eta), float(conv),
+                                           float(relFactor), int(max_iter), int(force_iters), C.byref(h)),
+              "negf_sigma_chain1d")
+        return h.value
+
+    def sigma_bethe(self, atom_orbs, atom_nbs, H, Slist, Vlist, xi, eta, conv, mix=0.5,
+                    max_iter=1000, force_iters=-1):
+        """atom_orbs[c][a] = 9 orbital indices; atom_nbs[c][a] = attached directions;
+        H[c] 9x9; Slist[c], Vlist[c] 12x9x9."""
+        n_atoms = np.array([len(c) for c in atom_orbs], dtype=np.int32)
+        orbs = np.ascontiguousarray(
+            np.concatenate([np.asarray(a, dtype=np.int32).ravel() for c in atom_orbs for a in c]), dtype=np.int32)
+        n_nb = np.array([len(a) for c in atom_nbs for a in c], dtype=np.int32)
+        flat = [int(v) for c in atom_nbs for a in c for v in a]
+        nb = np.array(flat if flat else [0], dtype=np.int32)
+        Hc = np.ascontiguousarray(np.stack([np.asarray(h, dtype=np.float64) for h in H]))
+        Sc = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in Slist]))
+        Vc = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in Vlist]))
+        assert Hc.shape[1:] == (9, 9) and Sc.shape[1:] == (12, 9, 9) and Vc.shape[1:] == (12, 9, 9)
+        xi_c = None if xi is None else _c128(xi, (self.n, self.n))
+        h = C.c_int(-1)
+        check(self._lib.negf_sigma_bethe(self._ctx, len(n_atoms), _ptr(n_atoms), _ptr(orbs), _ptr(n_nb),
+                                         _ptr(nb), _ptr(Hc), _ptr(Sc), _ptr(Vc), _ptr(xi_c), float(eta),
+                                         float(conv), float(mix), int(max_iter), int(force_iters),
+                                         C.byref(h)), "negf_sigma_bethe")
+        return h.value
+
+    def bethe_raw(self, H, Slist, Vlist, eta, conv, E, which, mix=0.5, max_iter=1000, force_iters=-1):
+        """surfGBAt.sigmaK (which=1 -> [m,12,9,9]) / surfGBAt.sigma (which=2 -> [m,9,9,9])."""
+        E, _ = self._grid(E)
+        Hc = np.ascontiguousarray(H, dtype=np.float64)
+        Sc = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in Slist]))
+        Vc = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in Vlist]))
+        assert Hc.shape == (9, 9) and Sc.shape == (12, 9, 9) and Vc.shape == (12, 9, 9)
+        nd = 12 if which == 1 else 9
+        out = np.zeros((E.size, nd, 9, 9), dtype=np.complex128)
+        iters = np.zeros(max(E.size, 1), dtype=np.int32)
+        conv_f = np.zeros(max(E.size, 1), dtype=np.int32)
+        check(self._lib.negf_bethe_raw(self._ctx, _ptr(Hc), _ptr(Sc), _ptr(Vc), float(eta), float(conv),
+                                       float(mix), int(max_iter), int(force_iters), int(which), E.size,
+                                       _ptr(E), _ptr(out), _ptr(iters), _ptr(conv_f)), "negf_bethe_raw")
+        self.last_iters = iters[:E.size]
+        self.last_converged = conv_f[:E.size]
+        return out
+
+    def sigma_precomputed(self, sigma_tot, sigma_c=None, gammas=None):
+        """sigma_tot [m,n,n]; sigma_c [m,n,n] or [m,k,n,n]; gammas [m,k,n,n] are used
+        as coupling matrices directly (mutually exclusive with sigma_c)."""
+        st = _c128(sigma_tot)
+        m = st.shape[0]
+        assert st.shape[1:] == (self.n, self.n)
+        ncc, sc = 0, None
+        if gammas is not None:
+            sc = _c128(gammas)
+            assert sc.ndim == 4 and sc.shape[0] == m
+            ncc = -sc.shape[1]
+        elif sigma_c is not None:
+            sc = _c128(sigma_c)
+            if sc.ndim == 3:
+                sc = sc[:, None]
+            assert sc.shape[0] == m
+            ncc = sc.shape[1]
+            sc = np.ascontiguousarray(sc)
+        h = C.c_int(-1)
+        check(self._lib.negf_sigma_precomputed(self._ctx, m, _ptr(st), ncc, _ptr(sc), C.byref(h)),
+              "negf_sigma_precomputed")
+        return h.value
+
+    def sigma_free(self, handle):
+        if getattr(self, "_ctx", None):
+            self._lib.negf_sigma_free(self._ctx, int(handle))
+
+    # -------------------------------------------------------------- hot path
+    def _grid(self, E, w=None):
+        E = np.ascontiguousarray(np.asarray(E).ravel(), dtype=np.complex128)
+        if w is None:
+            return E, None
+        w = np.ascontiguousarray(np.asarray(w).ravel(), dtype=np.complex128)
+        assert E.size == w.size, "Elist and weights must have the same length"
+        return E, w
+
+    def _numerical(self, rc, info, where):
+        self.last_info = info
+        if rc == _lib.NEGF_ESINGULAR:
+            bad = np.nonzero(info)[0]
+            warnings.warn(f"{where}: exactly singular E*S-F-Sigma at energy indices {bad[:8].tolist()}"
+                          f"{'...' if bad.size > 8 else ''}", RuntimeWarning)
+
+    def gr_int(self, handle, E, w):
+        E, w = self._grid(E, w)
+        out = np.zeros((self.n, self.n), dtype=np.complex128)
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_gr_int(self._ctx, handle, E.size, _ptr(E), _ptr(w), _ptr(out), _ptr(info)),
+                   "negf_gr_int")
+        self._numerical(rc, info[:E.size], "gr_int")
+        return out
+
+    def gless_int(self, handle, ind, E, w):
+        E, w = self._grid(E, w)
+        out = np.zeros((self.n, self.n), dtype=np.complex128)
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_gless_int(self._ctx, handle, _ind(ind), E.size, _ptr(E), _ptr(w),
+                                            _ptr(out), _ptr(info)), "negf_gless_int")
+        self._numerical(rc, info[:E.size], "gless_int")
+        return out
+
+    def gr_batch(self, handle, E):
+        E, _ = self._grid(E)
+        out = np.zeros((E.size, self.n, self.n), dtype=np.complex128)
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_gr_batch(self._ctx, handle, E.size, _ptr(E), _ptr(out), _ptr(info)),
+                   "negf_gr_batch")
+        self._numerical(rc, info[:E.size], "gr_batch")
+        return out
+
+    def transmission(self, handle, contact_L, contact_R, E, spin_block=False):
+        E, _ = self._grid(E)
+        T = np.zeros(E.size, dtype=np.float64)
+        Ts = np.zeros((E.size, 4), dtype=np.float64) if spin_block else None
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        mode = NEGF_SPIN_BLOCK if spin_block else NEGF_SPIN_RESTRICTED
+        rc = check(self._lib.negf_transmission(self._ctx, handle, int(contact_L), int(contact_R), mode,
+                                               E.size, _ptr(E), _ptr(T), _ptr(Ts), _ptr(info)),
+                   "negf_transmission")
+        self._numerical(rc, info[:E.size], "transmission")
+        return (T, Ts) if spin_block else T
+
+    def dos(self, handle, E, per_site=True):
+        E, _ = self._grid(E)
+        tot = np.zeros(E.size, dtype=np.float64)
+        site = np.zeros((E.size, self.n), dtype=np.float64) if per_site else None
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_dos(self._ctx, handle, E.size, _ptr(E), _ptr(tot), _ptr(site), _ptr(info)),
+                   "negf_dos")
+        self._numerical(rc, info[:E.size], "dos")
+        return (tot, site) if per_site else tot
+
+    def sigma_eval(self, handle, contact, E, n_contacts=1):
+        E, _ = self._grid(E)
+        out = np.zeros((E.size, self.n, self.n), dtype=np.complex128)
+        iters = np.zeros((max(E.size, 1), max(n_contacts, 1)), dtype=np.int32)
+        conv = np.zeros((max(E.size, 1), max(n_contacts, 1)), dtype=np.int32)
+        check(self._lib.negf_sigma_eval(self._ctx, handle, _ind(contact), E.size, _ptr(E), _ptr(out),
+                                        _ptr(iters), _ptr(conv)), "negf_sigma_eval")
+        self.last_iters = iters[:E.size]
+        self.last_converged = conv[:E.size]
+        return out
+
+    # -------------------------------------------------- device-resident calls
+    def gr_int_dev(self, handle, m, E_ptr, w_ptr, out_ptr):
+        check(self._lib.negf_gr_int_dev(self._ctx, handle, int(m), C.c_void_p(E_ptr), C.c_void_p(w_ptr),
+                                        C.c_void_p(out_ptr)), "negf_gr_int_dev")
+
+    def gless_int_dev(self, handle, ind, m, E_ptr, w_ptr, out_ptr):
+        check(self._lib.negf_gless_int_dev(self._ctx, handle, _ind(ind), int(m), C.c_void_p(E_ptr),
+                                           C.c_void_p(w_ptr), C.c_void_p(out_ptr)), "negf_gless_int_dev")
+
+    def transmission_dev(self, handle, contact_L, contact_R, m, E_ptr, T_ptr, Tspin_ptr=0, spin_block=False):
+        mode = NEGF_SPIN_BLOCK if spin_block else NEGF_SPIN_RESTRICTED
+        check(self._lib.negf_transmission_dev(self._ctx, handle, int(contact_L), int(contact_R), mode, int(m),
+                                              C.c_void_p(E_ptr), C.c_void_p(T_ptr),
+                                              C.c_void_p(Tspin_ptr or 0)), "negf_transmission_dev")
+
+    def last_info_dev(self, m):
+        info = np.zeros(max(m, 1), dtype=np.int32)
+        check(self._lib.negf_last_info(self._ctx, int(m), _ptr(info)), "negf_last_info")
+        return info[:m]
+
+    # ---------------------------------------------------------- diagnostics
+    def profile(self, on=True):
+        check(self._lib.negf_profile_enable(self._ctx, 1 if on else 0), "negf_profile_enable")
+
+    def profile_reset(self):
+        check(self._lib.negf_profile_reset(self._ctx), "negf_profile_reset")
+
+    def profile_read(self, family):
+        ms = C.c_double(0.0)
+        n = C.c_int(0)
+        check(self._lib.negf_profile_read(self._ctx, family.encode(), C.byref(ms), C.byref(n)),
+              "negf_profile_read")
+        return ms.value, n.value
+
+    def selftest_mfma(self):
+        err = C.c_double(-1.0)
+        check(self._lib.negf_selftest_mfma(self._ctx, C.byref(err)), "negf_selftest_mfma")
+        return err.value
+
+
+def get_engine(device=None):
+    """Process-wide engine for ``device`` (default: LOCAL_RANK, else 0)."""
+    key = device
+    if key not in _engines:
+        _engines[key] = Engine(device)
+    return _engines[key]
+
+
+def reset_engines():
+    for e in _engines.values():
+        e.close()
+    _engines.clear()

@@ -1,0 +1,419 @@
+"""
+Transmission, DOS and current -- drop-in for gauNEGF/transport.py.
+
+The reference walks the energy list in a Python loop, one jitted call and one
+device->host sync per energy (transport.py:452-469, 567-591).  Here the host keeps
+exactly the same bookkeeping (``-1`` sentinels, ``.npz`` checkpoint keys, resume
+check, ``np.arange`` current grid, trapezoid rule, e/h and spin factors) and hands
+every chunk of uncalculated energies to the GPU in one call: per energy one blocked
+Gauss-Jordan inverse, two complex GEMMs on the FP64 matrix cores and a wavefront
+trace reduction.
+"""
+import os
+
+import numpy as np
+from scipy.integrate import trapezoid
+
+from . import distributed as _dist
+from .config import ENERGY_STEP, N_KT, TEMPERATURE
+from .engine import get_engine
+
+# CONSTANTS (transport.py:33-37)
+har_to_eV = 27.211386   # eV/Hartree
+eoverh = 3.874e-5       # A/eV
+kB = 8.617e-5           # eV/Kelvin
+V_to_au = 0.03675       # Volts to Hartree/elementary Charge
+
+GPU_CHUNK = 512         # energies per engine call when checkpointing is on
+
+
+class SigmaCalculator:
+    """Uniform access to static (sig1, sig2) arrays or an energy-dependent surfG-like
+    object (transport.py:40-146): ``get_sigma_total / get_sigma / get_gamma`` with the
+    reference's spin expansion (kron(I2, s) for 'u'/'ro', kron(s, I2) for 'g' when
+    the Fock matrix is twice the size of sigma)."""
+
+    def __init__(self, sig1, sig2=None, energy_dependent=None):
+        self.sig1 = sig1
+        self.sig2 = sig2
+        if energy_dependent is None:
+            self.energy_dependent = hasattr(sig1, 'sigma') and hasattr(sig1, 'sigmaTot')
+        else:
+            self.energy_dependent = energy_dependent
+        if self.energy_dependent and sig2 is not None:
+            raise ValueError("For energy-dependent calculations, provide only surfG object as sig1")
+        if not self.energy_dependent and sig2 is None:
+            raise ValueError("For energy-independent calculations, provide both sig1 and sig2")
+
+    @staticmethod
+    def _expand(sigma, spin, matrix_size):
+        if spin in ['u', 'ro', 'g'] and matrix_size is not None and matrix_size == 2 * sigma.shape[0]:
+            if spin in ['u', 'ro']:
+                return np.kron(np.eye(2), sigma)
+            return np.kron(sigma, np.eye(2))
+        return sigma
+
+    @staticmethod
+    def _static(sig):
+        a = np.asarray(sig)
+        return np.diag(a) if a.ndim == 1 else a
+
+    def get_sigma_total(self, E, spin=None, matrix_size=None):
+        if self.energy_dependent:
+            total = self.sig1.sigmaTot(E)
+        else:
+            a1, a2 = np.asarray(self.sig1), np.asarray(self.sig2)
+            total = np.diag(a1 + a2) if a1.ndim == 1 else a1 + a2
+        return self._expand(total, spin, matrix_size)
+
+    def get_sigma(self, E, contact_index, spin=None, matrix_size=None):
+        if self.energy_dependent:
+            sigma = self.sig1.sigma(E, contact_index)
+        else:
+            if contact_index == 0:
+                sigma = self._static(self.sig1)
+            elif contact_index == -1 or contact_index == 1:
+                sigma = self._static(self.sig2)
+            else:
+                raise ValueError(f"Invalid contact_index {contact_index}")
+        return self._expand(sigma, spin, matrix_size)
+
+    def get_gamma(self, E, contact_index, spin=None, matrix_size=None):
+        sigma = self.get_sigma(E, contact_index, spin, matrix_size)
+        return 1j * (sigma - np.conj(sigma).T)
+
+    # ---- engine lowering ---------------------------------------------------
+    def _lower(self, engine, energies, spin, matrix_size):
+        """Provider handle serving Sigma_tot, Sigma_L (contact 0) and Sigma_R (contact -1)
+        for ``energies``.  Returns (handle, temporary)."""
+        if not self.energy_dependent:
+            s1 = self._expand(self._static(self.sig1), spin, matrix_size)
+            s2 = self._expand(self._static(self.sig2), spin, matrix_size)
+            return engine.sigma_const([s1, s2]), True
+        g = self.sig1
+        native = hasattr(g, "_negf_lower")
+        sig_size = getattr(g, "F", np.zeros((matrix_size, matrix_size))).shape[0] if native else None
+        if native and sig_size == matrix_size and getattr(g, "num_contacts", 2) >= 1:
+            return g._negf_lower(engine), False
+        # spin-expanded or foreign provider: evaluate the three matrices per energy and
+        # stage them (expansion is index bookkeeping; the Green's functions stay on the GPU)
+        tot = np.stack([np.asarray(self.get_sigma_total(E, spin, matrix_size)) for E in energies])
+        sL = np.stack([np.asarray(self.get_sigma(E, 0, spin, matrix_size)) for E in energies])
+        sR = np.stack([np.asarray(self.get_sigma(E, -1, spin, matrix_size)) for E in energies])
+        return engine.sigma_precomputed(tot, np.stack([sL, sR], axis=1)), True
+
+
+# --------------------------------------------------------------------------- #
+# per-energy kernels with explicit matrices (names imported by reference users,
+# tests/jax_optimization_suite.py:36-37)
+# --------------------------------------------------------------------------- #
+def _explicit(E, F, S, sigma_total, gammas=None):
+    eng = get_engine()
+    eng.set_system(F, S)
+    st = np.asarray(sigma_total)[None]
+    gm = None if gammas is None else np.stack([np.asarray(x) for x in gammas])[None]
+    return eng, eng.sigma_precomputed(st, gammas=gm)
+
+
+def _transmission_kernel_restricted(E, F, S, sigma_total, gamma1, gamma2):
+    """Re Tr[gamma1 G gamma2 G^H] (transport.py:150-157)."""
+    eng, h = _explicit(E, F, S, sigma_total, (gamma1, gamma2))
+    try:
+        return float(eng.transmission(h, 0, 1, [E])[0])
+    finally:
+        eng.sigma_free(h)
+
+
+def _transmission_kernel_spin_block(E, F, S, sigma_total, gamma1, gamma2):
+    """(sum, [uu, ud, du, dd]) for 2N x 2N block-form matrices (transport.py:159-181)."""
+    eng, h = _explicit(E, F, S, sigma_total, (gamma1, gamma2))
+    try:
+        T, Ts = eng.transmission(h, 0, 1, [E], spin_block=True)
+        return float(T[0]), Ts[0]
+    finally:
+        eng.sigma_free(h)
+
+
+def _dos_kernel(E, F, S, sigma_total):
+    """(total, per-site) DOS = -Im diag(G)/pi (transport.py:183-190)."""
+    eng, h = _explicit(E, F, S, sigma_total)
+    try:
+        tot, site = eng.dos(h, [E])
+        return float(tot[0]), site[0]
+    finally:
+        eng.sigma_free(h)
+
+
+# --------------------------------------------------------------------------- #
+# batched evaluation used by the front-ends
+# --------------------------------------------------------------------------- #
+def _spinor_perm(N):
+    # spinor [a0,b0,a1,b1,...] -> block [a0,a1,...,b0,b1,...] (transport.py:255)
+    return np.concatenate([np.arange(0, 2 * N, 2), np.arange(1, 2 * N, 2)])
+
+
+def _transmission_batch(F, S, sigma_calc, energies, spin):
+    """T(E) for all ``energies`` on the GPU: array [m] ('r') or ([m], [m,4])."""
+    if spin not in ('r', 'u', 'ro', 'g'):
+        raise ValueError(f"Unknown spin configuration '{spin}'. Use 'r', 'u', 'ro', or 'g'")
+    energies = np.asarray(energies)
+    F = np.asarray(F)
+    S = np.asarray(S)
+    eng = get_engine()
+    size = F.shape[0]
+    if spin == 'g':
+        # shuffle everything to block form, as the reference does before its kernel
+        perm = _spinor_perm(size // 2)
+        ix = np.ix_(perm, perm)
+        tot = np.stack([np.asarray(sigma_calc.get_sigma_total(E, spin, size))[ix] for E in energies])
+        sL = np.stack([np.asarray(sigma_calc.get_sigma(E, 0, spin, size))[ix] for E in energies])
+        sR = np.stack([np.asarray(sigma_calc.get_sigma(E, -1, spin, size))[ix] for E in energies])
+        eng.set_system(F[ix], S[ix])
+        h, temp = eng.sigma_precomputed(tot, np.stack([sL, sR], axis=1)), True
+    else:
+        eng.set_system(F, S)
+        h, temp = sigma_calc._lower(eng, energies, spin, size)
+    try:
+        if spin == 'r':
+            return eng.transmission(h, 0, -1, energies)
+        return eng.transmission(h, 0, -1, energies, spin_block=True)
+    finally:
+        if temp:
+            eng.sigma_free(h)
+
+
+def _dos_batch(F, S, sigma_calc, energies, spin):
+    F = np.asarray(F)
+    S = np.asarray(S)
+    eng = get_engine()
+    eng.set_system(F, S)
+    size = F.shape[0]
+    if sigma_calc.energy_dependent and hasattr(sigma_calc.sig1, "_negf_lower") and \
+            getattr(sigma_calc.sig1, "F", F).shape[0] == size:
+        h, temp = sigma_calc.sig1._negf_lower(eng), False
+    elif not sigma_calc.energy_dependent:
+        tot = np.asarray(sigma_calc.get_sigma_total(0.0, spin, size))
+        h, temp = eng.sigma_const([tot]), True
+    else:
+        tot = np.stack([np.asarray(sigma_calc.get_sigma_total(E, spin, size)) for E in energies])
+        h, temp = eng.sigma_precomputed(tot), True
+    try:
+        return eng.dos(h, energies)
+    finally:
+        if temp:
+            eng.sigma_free(h)
+
+
+def transmission_single_energy(E, F_jax, S_jax, sigma_calc, spin=None):
+    """transport.py:193-271: float for 'r', (total, [4]) otherwise."""
+    if spin is None:
+        spin = 'r'
+    res = _transmission_batch(F_jax, S_jax, sigma_calc, np.array([E]), spin)
+    if spin == 'r':
+        return float(res[0])
+    return float(res[0][0]), res[1][0].tolist()
+
+
+def dos_single_energy(E, F_jax, S_jax, sigma_calc, spin=None):
+    """transport.py:273-373."""
+    if spin is None:
+        spin = 'r'
+    if spin not in ('r', 'u', 'ro', 'g'):
+        raise ValueError(f"Unknown spin configuration '{spin}'. Use 'r', 'u', 'ro', or 'g'")
+    tot, site = _dos_batch(F_jax, S_jax, sigma_calc, np.array([E]), spin)
+    return _dos_result(float(tot[0]), site[0], spin)
+
+
+def _dos_result(total, per_site, spin):
+    if spin == 'r':
+        return total, np.array(per_site)
+    N = per_site.shape[0] // 2
+    if spin in ('u', 'ro'):
+        up, down = per_site[:N], per_site[N:]
+        per = np.concatenate([up, down])
+        return np.sum(up) + np.sum(down), per, up, down
+    up, down = per_site[0::2], per_site[1::2]          # 'g': alpha / beta spinor components
+    return np.sum(per_site), per_site, up, down
+
+
+# --------------------------------------------------------------------------- #
+# front-ends with the reference's checkpoint semantics
+# --------------------------------------------------------------------------- #
+def _chunks(remaining, checkpoint_file, checkpoint_interval):
+    if not checkpoint_file:
+        return [remaining] if len(remaining) else []
+    step = max(int(checkpoint_interval), 1)
+    step = ((GPU_CHUNK + step - 1) // step) * step       # a multiple of the save interval
+    return [remaining[a:a + step] for a in range(0, len(remaining), step)]
+
+
+def calculate_transmission(F, S, sigma_calculator, energy_list, spin=None, checkpoint_file=None,
+                           checkpoint_interval=10):
+    """T(E) over ``energy_list`` with ``.npz`` checkpointing (transport.py:376-483):
+    -1 marks uncalculated energies; an existing checkpoint whose energy list matches
+    (rtol 1e-10) is resumed; keys ``transmission``, ``spin_transmission``, ``energy_list``."""
+    energy_list = np.asarray(energy_list)
+    n_energies = len(energy_list)
+    if spin is None:
+        spin = 'r'
+    spin_open = spin in ['u', 'ro', 'g']
+
+    transmission = -1 * np.ones(n_energies)
+    spin_trans = -1 * np.ones((n_energies, 4)) if spin_open else None
+    if checkpoint_file and os.path.exists(checkpoint_file):
+        data = np.load(checkpoint_file, allow_pickle=True)
+        if 'energy_list' in data:
+            if not np.allclose(data['energy_list'], energy_list, rtol=1e-10):
+                # (the reference leaves spin_transmission unallocated on this branch and then
+                # fails at :459 for open-shell spins; a fresh start is what its message says)
+                print("Warning: energy_list in checkpoint doesn't match. Starting fresh.")
+            else:
+                if 'transmission' in data:
+                    transmission = data['transmission']
+                if spin_open and 'spin_transmission' in data:
+                    spin_trans = data['spin_transmission']
+
+    def save():
+        if spin_trans is not None:
+            np.savez(checkpoint_file, transmission=transmission, spin_transmission=spin_trans,
+                     energy_list=energy_list)
+        else:
+            np.savez(checkpoint_file, transmission=transmission, energy_list=energy_list)
+
+    remaining = np.where(transmission == -1)[0]
+    for chunk in _chunks(remaining, checkpoint_file, checkpoint_interval):
+        E = energy_list[chunk]
+        if spin == 'r':
+            transmission[chunk] = _dist.sharded_map(
+                lambda idx: _transmission_batch(F, S, sigma_calculator, E[idx], spin), len(chunk))
+        else:
+            def both(idx):
+                T, Ts = _transmission_batch(F, S, sigma_calculator, E[idx], spin)
+                return np.concatenate([T[:, None], Ts], axis=1)
+            res = _dist.sharded_map(both, len(chunk), (5,))
+            transmission[chunk] = res[:, 0]
+            spin_trans[chunk] = res[:, 1:]
+        if checkpoint_file:
+            save()
+    if checkpoint_file:
+        save()
+    if spin_trans is not None:
+        return transmission, spin_trans
+    return transmission
+
+
+def calculate_dos(F, S, sigma_calculator, energy_list, spin=None, checkpoint_file=None,
+                  checkpoint_interval=10):
+    """DOS over ``energy_list`` with checkpointing (transport.py:486-607): keys ``dos_total``,
+    ``dos_per_site``, ``dos_spin``, ``energy_list``."""
+    energy_list = np.asarray(energy_list)
+    n_energies = len(energy_list)
+    n_sites = F.shape[0]
+    if spin is None:
+        spin = 'r'
+    if spin not in ('r', 'u', 'ro', 'g'):
+        raise ValueError(f"Unknown spin configuration '{spin}'. Use 'r', 'u', 'ro', or 'g'")
+    spin_open = spin in ['u', 'ro', 'g']
+
+    dos_total = -1 * np.ones(n_energies)
+    dos_per_site = -1 * np.ones((n_energies, n_sites))
+    dos_spin = -1 * np.ones((n_energies, 2)) if spin_open else None
+    if checkpoint_file and os.path.exists(checkpoint_file):
+        data = np.load(checkpoint_file, allow_pickle=True)
+        if 'energy_list' in data:
+            if not np.allclose(data['energy_list'], energy_list, rtol=1e-10):
+                print("Warning: energy_list in checkpoint doesn't match. Starting fresh.")
+            else:
+                if 'dos_total' in data:
+                    dos_total = data['dos_total']
+                if 'dos_per_site' in data:
+                    dos_per_site = data['dos_per_site']
+                if spin_open and 'dos_spin' in data:
+                    dos_spin = data['dos_spin']
+
+    def save():
+        if dos_spin is not None:
+            np.savez(checkpoint_file, dos_total=dos_total, dos_per_site=dos_per_site, dos_spin=dos_spin,
+                     energy_list=energy_list)
+        else:
+            np.savez(checkpoint_file, dos_total=dos_total, dos_per_site=dos_per_site,
+                     energy_list=energy_list)
+
+    remaining = np.where(dos_total == -1)[0]
+    for chunk in _chunks(remaining, checkpoint_file, checkpoint_interval):
+        E = energy_list[chunk]
+
+        def both(idx):
+            tot, site = _dos_batch(F, S, sigma_calculator, E[idx], spin)
+            return np.concatenate([tot[:, None], site], axis=1)
+        res = _dist.sharded_map(both, len(chunk), (n_sites + 1,))
+        for row, i in zip(res, chunk):
+            out = _dos_result(row[0], row[1:], spin)
+            dos_total[i] = out[0]
+            dos_per_site[i] = np.asarray(out[1])
+            if len(out) == 4:
+                dos_spin[i, 0] = np.sum(out[2])
+                dos_spin[i, 1] = np.sum(out[3])
+        if checkpoint_file:
+            save()
+    if checkpoint_file:
+        save()
+    if dos_spin is not None:
+        return dos_total, dos_per_site, dos_spin
+    return dos_total, dos_per_site
+
+
+def current_grid(fermi, qV, T=TEMPERATURE, dE=ENERGY_STEP):
+    """Integration energies of calculate_current (transport.py:652-672): ``np.arange``
+    (end-exclusive) from muL to muR, padded by 10 kT when T > 0; the step takes the
+    sign of qV.  Returns (energies, muL, muR)."""
+    dE = -1 * abs(dE) if qV < 0 else abs(dE)
+    muL = fermi - qV / 2
+    muR = fermi + qV / 2
+    if T == 0:
+        energies = np.arange(muL, muR, dE)
+    else:
+        spread = np.sign(dE) * N_KT * kB * T
+        energies = np.arange(muL - spread, muR + spread, dE)
+    return energies, muL, muR
+
+
+def calculate_current(F, S, sigma_calculator, fermi, qV, T=TEMPERATURE, spin=None, dE=ENERGY_STEP,
+                      **kwargs):
+    """Landauer current at bias qV (transport.py:610-720)."""
+    if fermi is None or qV is None:
+        raise ValueError("fermi and qV must be provided for current calculations")
+    if spin is None:
+        spin = 'r'
+    if np.allclose(0, qV):
+        return 0.0 if spin == 'r' else [0.0, 0.0, 0.0, 0.0]
+    integration_energies, muL, muR = current_grid(fermi, qV, T, dE)
+    if len(integration_energies) == 0:
+        raise ValueError("No energies in integration window. Check fermi, qV, and dE.")
+
+    result = calculate_transmission(F, S, sigma_calculator, integration_energies, spin=spin, **kwargs)
+    if isinstance(result, tuple):
+        transmissions, spin_transmissions = np.asarray(result[0]), np.asarray(result[1])
+    else:
+        transmissions, spin_transmissions = np.asarray(result), None
+
+    if T == 0:
+        occupation = 1.0
+    else:
+        occupation = np.abs(1 / (np.exp((integration_energies - muR) / (kB * T)) + 1) -
+                            1 / (np.exp((integration_energies - muL) / (kB * T)) + 1))
+    if spin_transmissions is not None:
+        if T == 0:
+            current_spin = [eoverh * trapezoid(spin_transmissions[:, i], integration_energies)
+                            for i in range(4)]
+        else:
+            current_spin = [eoverh * trapezoid(spin_transmissions[:, i] * occupation, integration_energies)
+                            for i in range(4)]
+        return sum(current_spin), current_spin
+    if T == 0:
+        current_total = eoverh * trapezoid(transmissions, integration_energies)
+    else:
+        current_total = eoverh * trapezoid(transmissions * occupation, integration_energies)
+    if spin == 'r':
+        current_total *= 2
+    return current_total

@@ -1,0 +1,199 @@
+/*
+ * negf.h -- C ABI of libnegf_hip.so, the MI355X (gfx950) NEGF energy-grid engine.
+ *
+ * The reference (wliverno/GauNEGF) is pure Python and has no FFI of its own; the
+ * seams this library sits behind are its Python call sites.  Each entry point
+ * below names the reference function it replaces (file:line in the reference
+ * checkout).  gaunegf_amd/_lib.py binds exactly these symbols with ctypes and
+ * gaunegf_amd/{integrate,transport,density,surfG1D,surfGBethe}.py re-expose them
+ * under the reference's own names (GrInt, GrLessInt, calculate_transmission ...).
+ *
+ * Conventions
+ *   - complex128 arrays are interleaved (re,im) doubles, row-major (C order), i.e.
+ *     the memory of a C-contiguous numpy complex128 array.
+ *   - "host" pointers are ordinary CPU memory; "*_dev" pointers are HIP device
+ *     memory on the context's GPU (e.g. torch.Tensor.data_ptr()).
+ *   - the caller owns every buffer; nothing is retained after a call returns,
+ *     except data copied by negf_set_system / negf_sigma_* into the context.
+ *   - return 0 = ok, <0 = argument / runtime error, >0 = numerical condition
+ *     (NEGF_ESINGULAR: at least one energy hit an exactly zero pivot; info[k]
+ *     holds the 1-based pivot column for energy k, LAPACK style).  A self-energy
+ *     fixed point that stops at its iteration cap is NOT an error (the reference
+ *     stops silently too, surfG1D.py:290-293); it is reported via converged[].
+ *   - one negf_ctx per (process, GPU); calls are blocking unless noted and the
+ *     context is not thread-safe (mirrors FORCE_SYNCHRONOUS, integrate.py:56).
+ *   - there is NO CPU fallback: negf_create fails with NEGF_ENODEV without a GPU.
+ */
+#ifndef NEGF_H
+#define NEGF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct negf_ctx negf_ctx;
+
+#define NEGF_OK          0
+#define NEGF_EINVAL     (-1)
+#define NEGF_ENOMEM     (-2)
+#define NEGF_EHIP       (-3)
+#define NEGF_ENODEV     (-4)
+#define NEGF_ESTATE     (-5)
+#define NEGF_ESINGULAR    1
+
+/* contact selector for "use the total self-energy" (Python ind=None,
+ * integrate.py:201-204).  Other negative values index from the end like Python
+ * (ind=-1 is the last contact, scfE.py:441,444). */
+#define NEGF_IND_TOTAL  (-1000)
+
+/* spin layouts of transport.py:193-271 */
+#define NEGF_SPIN_RESTRICTED 0   /* 'r'                         */
+#define NEGF_SPIN_BLOCK      1   /* 'u' / 'ro' (and 'g' after the host permutes spinor -> block form) */
+
+/* ---------------------------------------------------------------- lifetime */
+int         negf_device_count(void);                 /* 0 when no GPU / no driver */
+int         negf_create(negf_ctx** out, int device);
+void        negf_destroy(negf_ctx* ctx);
+const char* negf_strerror(int code);
+const char* negf_version(void);
+/* launch everything on this hipStream_t (NULL = the default stream) */
+int         negf_set_stream(negf_ctx* ctx, void* hip_stream);
+/* energies processed per sweep of the workspace (0 = choose from n and free HBM);
+ * replaces MAX_VMAP_MEMORY_GB batching, integrate.py:55,100-142 */
+int         negf_set_batch(negf_ctx* ctx, int batch);
+int         negf_get_batch(negf_ctx* ctx);
+
+/* F,S of the device region: the (F, S) arguments of GrInt/GrLessInt
+ * (integrate.py:146,177) and of the transport kernels (transport.py:150-190).
+ * Both n*n complex128 (a real F is passed with zero imaginary parts). */
+int negf_set_system(negf_ctx* ctx, int n, const double* F_c128, const double* S_c128);
+
+/* ------------------------------------------------- self-energy providers
+ * A provider is the device-side lowering of the reference's duck-typed ``g``
+ * object (.sigma(E,i) / .sigmaTot(E)).  Handles are small
+ * non-negative ints owned by the context. */
+
+/* energy-independent Sigma: surfGTester.py:94-132 / SigmaCalculator static
+ * (sig1,sig2), transport.py:77-117.  sigma_c128 = [n_contacts][n][n]; the
+ * total is their sum in contact order. */
+int negf_sigma_const(negf_ctx* ctx, int n_contacts, const double* sigma_c128, int* handle);
+
+/* 1-D chain decimation provider: surfG1D.py:223-399.  Per contact c the block
+ * size nc[c] and orbital indices inds (concatenated), and the nc x nc complex128
+ * matrices alpha,Salpha,beta,Sbeta,tau,Stau (concatenated in contact order).
+ * eta/conv/relFactor/max_iter default in the reference to ETA=1e-6 (config.py:9),
+ * 1e-5 (config.py:15), 0.1 (config.py:16), 2000 (surfG1D.py:265).
+ * force_iters >= 0 runs exactly that many sweeps (parity at fixed trip count);
+ * pass -1 for the reference's data-dependent stopping rule. */
+int negf_sigma_chain1d(negf_ctx* ctx, int n_contacts, const int* nc, const int* inds,
+                       const double* alpha, const double* Salpha,
+                       const double* beta, const double* Sbeta,
+                       const double* tau, const double* Stau,
+                       double eta, double conv, double relFactor, int max_iter,
+                       int force_iters, int* handle);
+
+/* Bethe-lattice provider: surfGBethe.py:479-575, 958-1108.  Per contact: onsite
+ * H [9][9] and the 12 direction matrices S,V [12][9][9] (all float64), the list
+ * of contact atoms (orbital indices [n_atoms][9], concatenated over contacts) and
+ * for every atom its attached-direction list (n_nb[atom] entries of nb_dirs,
+ * concatenated).  xi_c128 = S^{1/2} [n][n] or NULL (applied as Xi sig Xi when the
+ * .bethe file has Ssss == 0, surfGBethe.py:530-533).  mix=0.5, max_iter=1000 in
+ * the reference (:958,:998). */
+int negf_sigma_bethe(negf_ctx* ctx, int n_contacts, const int* n_atoms,
+                     const int* atom_orbs, const int* n_nb, const int* nb_dirs,
+                     const double* H, const double* Slist, const double* Vlist,
+                     const double* xi_c128,
+                     double eta, double conv, double mix, int max_iter,
+                     int force_iters, int* handle);
+
+/* The single-atom Bethe lattice itself: surfGBAt.sigmaK (which = 1, out [m][12][9][9],
+ * surfGBethe.py:958-1030) or surfGBAt.sigma (which = 2, out [m][9][9][9], :1032-1108).
+ * H [9][9], Slist/Vlist [12][9][9] float64.  iters[m]: bulk sweeps (which = 1) or
+ * bulk + (surface << 16) (which = 2); converged[m] likewise (bit 0 bulk, bit 1 surface). */
+int negf_bethe_raw(negf_ctx* ctx, const double* H, const double* Slist, const double* Vlist,
+                   double eta, double conv, double mix, int max_iter, int force_iters,
+                   int which, int m, const double* E_c128, double* out_c128,
+                   int* iters, int* converged);
+
+/* Sigma evaluated by the caller for exactly the energies of the NEXT integral
+ * (arbitrary user ``g`` objects, integrate.py:169,203-204): sigma_tot [m][n][n]
+ * and, optionally, the contact Sigma_c used for Gamma [m][n][n] (NULL = use
+ * sigma_tot).  n_contacts_c > 1 means sigma_c holds [m][n_contacts_c][n][n].
+ * n_contacts_c < 0: sigma_c holds [m][-n_contacts_c][n][n] matrices that ARE the
+ * couplings Gamma (used as given instead of i(Sigma_c - Sigma_c^H)); this is how
+ * _transmission_kernel_restricted(E,F,S,sigma_total,gamma1,gamma2)
+ * (transport.py:150-157), whose gammas are arguments, is served. */
+int negf_sigma_precomputed(negf_ctx* ctx, int m, const double* sigma_tot_c128,
+                           int n_contacts_c, const double* sigma_c_c128, int* handle);
+
+int negf_sigma_free(negf_ctx* ctx, int handle);
+
+/* Sigma(E) itself: g.sigma(E,i) / g.sigmaTot(E) (surfG1D.py:344-399,
+ * surfGBethe.py:479-575).  contact = NEGF_IND_TOTAL or a contact index.
+ * sigma_out [m][n][n]; iters / converged are [m][n_contacts] (may be NULL). */
+int negf_sigma_eval(negf_ctx* ctx, int handle, int contact, int m, const double* E_c128,
+                    double* sigma_out_c128, int* iters, int* converged);
+
+/* ------------------------------------------------------------- the hot path */
+
+/* sum_m w_m G^r(E_m) -- GrInt, integrate.py:146-173 (+ _gr_matrix_ops :67-71,
+ * _GInt :84-142).  out [n][n]; info [m] or NULL. */
+int negf_gr_int(negf_ctx* ctx, int handle, int m, const double* E_c128,
+                const double* w_c128, double* out_c128, int* info);
+
+/* sum_m w_m G Gamma_c G^H -- GrLessInt, integrate.py:177-208 (+ :74-82). */
+int negf_gless_int(negf_ctx* ctx, int handle, int ind, int m, const double* E_c128,
+                   const double* w_c128, double* out_c128, int* info);
+
+/* every G^r(E_m) [m][n][n]; used by parity tests and by callers that need G(E). */
+int negf_gr_batch(negf_ctx* ctx, int handle, int m, const double* E_c128,
+                  double* G_out_c128, int* info);
+
+/* Re Tr[Gamma_L G Gamma_R G^H] per energy -- _transmission_kernel_restricted /
+ * _transmission_kernel_spin_block, transport.py:150-181.  T [m]; Tspin [m][4]
+ * (uu,ud,du,dd) or NULL, required for NEGF_SPIN_BLOCK. */
+int negf_transmission(negf_ctx* ctx, int handle, int contact_L, int contact_R,
+                      int spin_mode, int m, const double* E_c128,
+                      double* T, double* Tspin, int* info);
+
+/* -Im diag G / pi and its sum -- _dos_kernel transport.py:183-190,
+ * _compute_dos_at_energy density.py:49-54.  dos_site [m][n] or NULL. */
+int negf_dos(negf_ctx* ctx, int handle, int m, const double* E_c128,
+             double* dos_total, double* dos_site, int* info);
+
+/* ----------------------------------------------- device-resident variants
+ * Same operations with the energy grid, weights and result already in HBM on
+ * the context's GPU (used by bench.py and by the multi-GPU driver, which
+ * all-reduces out_dev with RCCL through torch.distributed).  Asynchronous on
+ * the context's stream; negf_sync waits.  negf_last_info copies the per-energy
+ * info of the last *_dev call. */
+int negf_gr_int_dev(negf_ctx* ctx, int handle, int m, const double* E_dev,
+                    const double* w_dev, double* out_dev);
+int negf_gless_int_dev(negf_ctx* ctx, int handle, int ind, int m, const double* E_dev,
+                       const double* w_dev, double* out_dev);
+int negf_transmission_dev(negf_ctx* ctx, int handle, int contact_L, int contact_R,
+                          int spin_mode, int m, const double* E_dev,
+                          double* T_dev, double* Tspin_dev);
+int negf_sync(negf_ctx* ctx);
+int negf_last_info(negf_ctx* ctx, int m, int* info);
+
+/* ------------------------------------------------------------- diagnostics */
+/* hipEvent timing of the library's own kernels, per kernel family
+ * ("inverse", "assemble", "accumulate", "zgemm", "trace", "chain1d", "bethe"). */
+int negf_profile_enable(negf_ctx* ctx, int on);
+int negf_profile_reset(negf_ctx* ctx);
+int negf_profile_read(negf_ctx* ctx, const char* family, double* total_ms, int* launches);
+/* choose the inverse kernel: 0 = auto, 1 = unblocked Gauss-Jordan (any n),
+ * 2 = blocked Gauss-Jordan with FP64 MFMA trailing updates */
+int negf_set_inverse_algo(negf_ctx* ctx, int algo);
+/* run the FP64 MFMA fragment-layout probe; max abs error vs an exact integer
+ * product (0.0 expected) */
+int negf_selftest_mfma(negf_ctx* ctx, double* max_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEGF_H */

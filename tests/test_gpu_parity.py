@@ -1,0 +1,447 @@
+"""
+Parity of the HIP engine (through the C ABI) against the numpy oracle and the
+committed golden vectors.  Run on the MI355X box:  pytest tests -m gpu
+
+Tolerances (BASELINE.json north_star): grid bookkeeping bit-exact (test_grids.py);
+complex128 G(E) and everything derived from it within 1e-8 RELATIVE FROBENIUS of
+the reference CPU path (TOL below; observed errors are ~1e-13).  Self-energy
+fixed points are compared at a fixed trip count (1e-10) and, free running, within
+10*conv (SURVEY.md section 7 "Fixed-point semantics").
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import MockSigma, chain_lead, const_sigma_pair, random_system, rel_fro
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+# --------------------------------------------------------------------------- #
+def _const_provider(N, seed, nc=None, gamma=0.1):
+    from gaunegf_amd.surfGTester import surfGTest
+    F, S = random_system(N, seed)
+    nc = nc or max(1, N // 10)
+    inds, s1, s2 = const_sigma_pair(N, S, nc, gamma)
+    g_dev = surfGTest(F, S, inds, -1j * gamma)
+    g_ref = oracle.ConstSigma(F, S, inds, -1j * gamma)
+    return F, S, g_dev, g_ref
+
+
+def test_mfma_fragment_layout(engine):
+    assert engine.selftest_mfma() == 0.0
+
+
+def test_library_is_loaded_in_process():
+    # the round-end check looks for the in-tree .so among the loaded objects
+    maps = open("/proc/self/maps").read()
+    from gaunegf_amd.engine import get_engine
+    get_engine()
+    maps = open("/proc/self/maps").read()
+    assert "libnegf_hip.so" in maps
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("N", [1, 3, 17, 32, 40, 64, 100, 200])
+def test_G_of_E_per_energy(engine, N, algo):
+    """G(E) = solve(E S - F - Sigma, I) for every energy, both inverse kernels."""
+    from gaunegf_amd.integrate import GrBatch
+    F, S, g_dev, g_ref = _const_provider(N, 100 + N)
+    E = np.concatenate([np.linspace(-3, 3, 9), np.array([0.3 + 0.5j, -1.2 + 2j, 0.05 + 1e-3j])])
+    engine.set_inverse_algo(algo)
+    try:
+        G = GrBatch(F, S, g_dev, E)
+    finally:
+        engine.set_inverse_algo(0)
+    ref = oracle.gr_batch(F, S, g_ref, E)
+    for k in range(len(E)):
+        assert rel_fro(G[k], ref[k]) < TOL, (N, algo, k, rel_fro(G[k], ref[k]))
+
+
+@pytest.mark.parametrize("N,M", [(12, 12), (60, 100), (200, 64)])
+def test_GrInt_GrLessInt_const_sigma(engine, N, M):
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    F, S, g_dev, g_ref = _const_provider(N, 7 + N)
+    E, w = oracle.contour_grid(-4.0, 0.2, M if M % 2 == 0 else M + 1, 300.0)
+    assert rel_fro(GrInt(F, S, g_dev, E, w), oracle.GrInt(F, S, g_ref, E, w)) < TOL
+    Eg, wg = oracle.bias_window_grid(-0.25, 0.25, M, 300.0)
+    for ind in (None, 0, -1, 1):
+        got = GrLessInt(F, S, g_dev, Eg, wg, ind)
+        assert rel_fro(got, oracle.GrLessInt(F, S, g_ref, Eg, wg, ind)) < TOL, ind
+
+
+@pytest.mark.parametrize("size", [12, 40])
+def test_reference_consistency_vectors(engine, golden_num, size):
+    """The reference's own consistency test (tests/test_computation_consistency.py):
+    its numpy loops' outputs are the golden values; a foreign provider goes through
+    the host-callback path."""
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    g = golden_num
+    F, S = g[f"cc{size}_F"], g[f"cc{size}_S"]
+    prov = MockSigma(g[f"cc{size}_sigma_base"], [g[f"cc{size}_sigma_c0"], g[f"cc{size}_sigma_c1"]])
+    E, w = g[f"cc{size}_E"], g[f"cc{size}_w"]
+    assert rel_fro(GrInt(F, S, prov, E, w), g[f"cc{size}_gr"]) < TOL
+    assert rel_fro(GrLessInt(F, S, prov, E, w), g[f"cc{size}_gless_none"]) < TOL
+    assert rel_fro(GrLessInt(F, S, prov, E, w, 0), g[f"cc{size}_gless_0"]) < TOL
+    assert rel_fro(GrLessInt(F, S, prov, E, w, 1), g[f"cc{size}_gless_1"]) < TOL
+    # the reference grades max-abs error < 1e-10 as "GOOD - consistent" (:226-233)
+    assert np.max(np.abs(GrInt(F, S, prov, E, w) - g[f"cc{size}_gr"])) < 1e-10
+
+
+def test_api_assertions_and_edges(engine):
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    F, S, g_dev, g_ref = _const_provider(8, 3)
+    with pytest.raises(AssertionError, match="same length"):
+        GrInt(F, S, g_dev, np.array([0.1, 0.2]), np.array([1.0]))
+    with pytest.raises(AssertionError, match="same shape"):
+        GrInt(F, S[:4, :4], g_dev, np.array([0.1]), np.array([1.0]))
+    # empty grid (callers pass boolean-masked slices that may be empty, density.py:254)
+    out = GrInt(F, S, g_dev, np.array([]), np.array([]))
+    assert out.shape == (8, 8) and not np.any(out)
+    # a single point, and a workspace batch smaller than the grid (multi-sweep)
+    E, w = oracle.real_axis_grid(-3, 0.1, 23, 300.0)
+    ref = oracle.GrInt(F, S, g_ref, E, w)
+    engine.set_batch(5)
+    try:
+        assert rel_fro(GrInt(F, S, g_dev, E, w), ref) < TOL
+        assert rel_fro(GrLessInt(F, S, g_dev, E, w, -1), oracle.GrLessInt(F, S, g_ref, E, w, -1)) < TOL
+    finally:
+        engine.set_batch(0)
+    assert rel_fro(GrInt(F, S, g_dev, E[:1], w[:1]), oracle.GrInt(F, S, g_ref, E[:1], w[:1])) < TOL
+    # invalid contact index
+    from gaunegf_amd._lib import NegfError
+    with pytest.raises(NegfError):
+        GrLessInt(F, S, g_dev, E, w, 5)
+
+
+def test_singular_matrix_is_reported(engine):
+    from gaunegf_amd.integrate import GrInt
+    from gaunegf_amd.surfGTester import surfGTest
+    N = 6
+    F = np.zeros((N, N)); S = np.eye(N)
+
+    class Zero:
+        def sigmaTot(self, E): return np.zeros((N, N), dtype=complex)
+        def sigma(self, E, i): return np.zeros((N, N), dtype=complex)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        GrInt(F, S, Zero(), np.array([0.0, 1.0]), np.array([1.0, 1.0]))     # E=0: A == 0 exactly
+    assert any("singular" in str(r.message) for r in rec)
+    assert engine.last_info[0] == 1 and engine.last_info[1] == 0
+
+
+def test_transmission_and_dos_golden(engine, golden_num):
+    """tests/jax_optimization_suite.py: kernels with explicit sigma / gamma matrices."""
+    from gaunegf_amd.transport import _transmission_kernel_restricted, _dos_kernel
+    from gaunegf_amd.density import _compute_dos_at_energy
+    g = golden_num
+    F, S, st, G1, G2 = (g[f"rts24_{k}"] for k in ("F", "S", "sigma", "G1", "G2"))
+    for E, T, D in zip(g["rts24_energies"], g["rts24_T"], g["rts24_dos"]):
+        assert abs(_transmission_kernel_restricted(E, F, S, st, G1, G2) - T) < 1e-8 * max(1.0, abs(T))
+        tot, site = _dos_kernel(E, F, S, st)
+        assert abs(tot - D) < 1e-8 * max(1.0, abs(D))
+        assert abs(np.sum(site) - tot) < 1e-9 * max(1.0, abs(tot))
+        assert abs(_compute_dos_at_energy(E, F, S, st) - D) < 1e-8 * max(1.0, abs(D))
+
+
+@pytest.mark.parametrize("N", [20, 64, 150])
+def test_transmission_front_end(engine, N, tmp_path):
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission, calculate_dos, calculate_current
+    F, S = random_system(N, 40 + N)
+    inds, s1, s2 = const_sigma_pair(N, S, max(2, N // 10))
+    sc = SigmaCalculator(s1, s2)
+    E = np.linspace(-2, 2, 33)
+    T = calculate_transmission(F, S, sc, E)
+    g1 = sc.get_gamma(0, 0); g2 = sc.get_gamma(0, -1); st = sc.get_sigma_total(0)
+    ref = np.array([oracle.transmission_restricted(e, F, S, st, g1, g2) for e in E])
+    assert np.max(np.abs(T - ref) / np.maximum(1.0, np.abs(ref))) < TOL
+    assert np.all(T >= -1e-12) and np.all(np.isfinite(T))              # test_transport_checkpointing.py:331
+    # single-point == batch (rtol 1e-10, :343)
+    from gaunegf_amd.transport import transmission_single_energy
+    assert abs(transmission_single_energy(E[5], F, S, sc) - T[5]) <= 1e-10 * abs(T[5])
+    # checkpoint resume equality (:396)
+    ck = str(tmp_path / "ck.npz")
+    T1 = calculate_transmission(F, S, sc, E, checkpoint_file=ck, checkpoint_interval=7)
+    d = np.load(ck); part = d["transmission"].copy(); part[10:20] = -1
+    np.savez(ck, transmission=part, energy_list=E)
+    T2 = calculate_transmission(F, S, sc, E, checkpoint_file=ck, checkpoint_interval=7)
+    assert np.allclose(T1, T2, rtol=1e-10, atol=0) and np.allclose(T1, T, rtol=1e-10, atol=0)
+    # DOS: total = sum of sites (rtol 1e-9, :432), value vs oracle
+    tot, site = calculate_dos(F, S, sc, E)
+    assert np.allclose(site.sum(axis=1), tot, rtol=1e-9)
+    dref = np.array([oracle.dos_kernel(e, F, S, st)[0] for e in E])
+    assert np.max(np.abs(tot - dref) / np.maximum(1.0, np.abs(dref))) < TOL
+    # current: |I(+V)| == |I(-V)| (rtol 1e-6, :549), zero bias -> 0 (:520), value vs oracle
+    Ip = calculate_current(F, S, sc, 0.0, 0.1, T=0.0, dE=0.01)
+    Im = calculate_current(F, S, sc, 0.0, -0.1, T=0.0, dE=0.01)
+    assert abs(abs(Ip) - abs(Im)) <= 1e-6 * abs(Ip)
+    assert calculate_current(F, S, sc, 0.0, 0.0) == 0.0
+    grid, muL, muR = oracle.current_grid(0.0, 0.1, 0.0, 0.01)
+    Tg = np.array([oracle.transmission_restricted(e, F, S, st, g1, g2) for e in grid])
+    assert abs(Ip - oracle.current_from_transmission(Tg, grid, muL, muR, 0.0, 'r')) < 1e-8 * abs(Ip)
+
+
+@pytest.mark.parametrize("spin", ["u", "g"])
+def test_spin_block_transmission(engine, spin):
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+    N = 14
+    rng = np.random.default_rng(9)
+    Fa, Sa = random_system(N, 61)
+    Fb, _ = random_system(N, 62)
+    C = 0.05 * rng.standard_normal((N, N)); C = C + C.T
+    # block form: [[alpha, C],[C, beta]] (a little spin mixing so that ud/du are non-zero)
+    Fblk = np.block([[Fa, C], [C, Fb]]); Sblk = np.kron(np.eye(2), Sa)
+    inds, s1, s2 = const_sigma_pair(N, Sa, 3)
+    sc = SigmaCalculator(s1, s2)
+    E = np.linspace(-1.5, 1.5, 7)
+    if spin == 'u':
+        F, S = Fblk, Sblk
+    else:
+        perm = np.concatenate([np.arange(0, 2 * N, 2), np.arange(1, 2 * N, 2)])
+        inv = np.argsort(perm)
+        F, S = Fblk[np.ix_(inv, inv)], Sblk[np.ix_(inv, inv)]        # spinor layout
+    T, Ts = calculate_transmission(F, S, sc, E, spin=spin)
+    st = np.kron(np.eye(2), s1 + s2)
+    g1 = np.kron(np.eye(2), 1j * (s1 - s1.conj().T)); g2 = np.kron(np.eye(2), 1j * (s2 - s2.conj().T))
+    for k, e in enumerate(E):
+        tot, comp = oracle.transmission_spin_block(e, Fblk, Sblk, st, g1, g2)
+        assert np.max(np.abs(Ts[k] - comp)) < TOL * max(1.0, np.max(np.abs(comp)))
+        assert abs(T[k] - tot) < TOL * max(1.0, abs(tot))
+
+
+# --------------------------------------------------------------------------- #
+# 1-D chain decimation
+# --------------------------------------------------------------------------- #
+def _chain_system(N, nc, seed, eta):
+    from gaunegf_amd.surfG1D import surfG
+    F, S = random_system(N, seed)
+    left = list(range(nc)); right = list(range(N - nc, N))
+    aL = chain_lead(nc, seed + 1); aR = chain_lead(nc, seed + 2)
+    taus = [aL[2].copy(), aR[2].copy()]; staus = [aL[3].copy(), aR[3].copy()]
+    args = dict(taus=taus, staus=staus, alphas=[aL[0], aR[0]], aOverlaps=[aL[1], aR[1]],
+                betas=[aL[2], aR[2]], bOverlaps=[aL[3], aR[3]], eta=eta)
+    g_dev = surfG(F, S, [left, right], **args)
+    g_ref = oracle.Chain1DSigma(F, S, [left, right], taus, staus, [aL[0], aR[0]], [aL[1], aR[1]],
+                                [aL[2], aR[2]], [aL[3], aR[3]], eta=eta)
+    return F, S, g_dev, g_ref
+
+
+@pytest.mark.parametrize("nc", [4, 10, 20])
+def test_chain1d_fixed_trip_count(engine, nc):
+    """Same number of sweeps on both sides -> the iterate itself must agree."""
+    N = 3 * nc
+    F, S, g_dev, g_ref = _chain_system(N, nc, 70 + nc, 1e-4)
+    g_dev.force_iters = 40; g_ref.force_iters = 40
+    for E in (0.3, -0.8, 0.1 + 0.2j):
+        for i in (0, 1, -1):
+            assert rel_fro(g_dev.sigma(E, i), g_ref.sigma(E, i)) < 1e-10, (nc, E, i)
+        assert rel_fro(g_dev.sigmaTot(E), g_ref.sigmaTot(E)) < 1e-10
+        gi, _, _ = oracle.chain1d_g(E, g_ref.aList[0], g_ref.aSList[0], g_ref.bList[0], g_ref.bSList[0],
+                                    1e-4, force_iters=40)
+        assert rel_fro(g_dev.g(E, 0), gi) < 1e-10
+
+
+def test_chain1d_free_running(engine):
+    """Reference stopping rule: iteration counts agree (+-1 at a threshold crossing) and
+    Sigma within 10*conv relative."""
+    nc = 8
+    F, S, g_dev, g_ref = _chain_system(3 * nc, nc, 91, 1e-3)
+    E = np.linspace(-1.5, 1.5, 16)
+    sig, iters, conv = g_dev.sigma_batch(E)
+    for k, e in enumerate(E):
+        ref = g_ref.sigmaTot(e)
+        c0 = g_ref.last_iters[(complex(e), 0)][0]; c1 = g_ref.last_iters[(complex(e), 1)][0]
+        assert abs(int(iters[k, 0]) - c0) <= 1 and abs(int(iters[k, 1]) - c1) <= 1
+        assert rel_fro(sig[k], ref) < 10 * 1e-5
+    # and G(E) given the device Sigma: GrInt with the native provider vs oracle with
+    # the oracle's own free-running Sigma (differences bounded by the fixed-point tolerance)
+    from gaunegf_amd.integrate import GrInt
+    w = np.ones_like(E) * (E[1] - E[0])
+    assert rel_fro(GrInt(F, S, g_dev, E, w), oracle.GrInt(F, S, g_ref, E, w)) < 1e-3
+
+
+def test_chain1d_integrals_fixed_trip(engine):
+    """GrInt / GrLessInt / transmission with the device-side CHAIN1D provider at a fixed
+    trip count: identical Sigma(E) inputs -> 1e-8 on the integrals."""
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+    nc = 6
+    F, S, g_dev, g_ref = _chain_system(30, nc, 33, 1e-4)
+    g_dev.force_iters = 60; g_ref.force_iters = 60
+    E, w = oracle.bias_window_grid(-0.3, 0.3, 24, 300.0)
+    assert rel_fro(GrInt(F, S, g_dev, E, w), oracle.GrInt(F, S, g_ref, E, w)) < TOL
+    for ind in (None, 0, -1):
+        assert rel_fro(GrLessInt(F, S, g_dev, E, w, ind), oracle.GrLessInt(F, S, g_ref, E, w, ind)) < TOL
+    T = calculate_transmission(F, S, SigmaCalculator(g_dev), E)
+    for k, e in enumerate(E):
+        s0 = g_ref.sigma(e, 0); s1 = g_ref.sigma(e, -1)
+        ref = oracle.transmission_restricted(e, F, S, g_ref.sigmaTot(e), 1j * (s0 - s0.conj().T),
+                                             1j * (s1 - s1.conj().T))
+        assert abs(T[k] - ref) < TOL * max(1.0, abs(ref))
+
+
+def test_perfect_wire_closed_form(engine):
+    """Tight-binding chain t=-1, eps=0, S=I with exact 1-D leads: T(E)=1 inside the band
+    (SURVEY.md section 8c closed form), to O(eta, conv)."""
+    from gaunegf_amd.surfG1D import surfG
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+    N = 12
+    F = np.zeros((N, N))
+    for i in range(N - 1):
+        F[i, i + 1] = F[i + 1, i] = -1.0
+    S = np.eye(N)
+    one = np.array([[0.0]]); t = np.array([[-1.0]]); z = np.array([[0.0]]); I1 = np.array([[1.0]])
+    g = surfG(F, S, [[0], [N - 1]], taus=[t, t], staus=[z, z], alphas=[one, one], aOverlaps=[I1, I1],
+              betas=[t, t], bOverlaps=[z, z], eta=1e-6)
+    E = np.linspace(-1.5, 1.5, 11)
+    T = calculate_transmission(F, S, SigmaCalculator(g), E)
+    assert np.max(np.abs(T - 1.0)) < 5e-3
+    # closed-form surface Green's function g_s = (E - i sqrt(4 - E^2)) / 2 for |E| < 2
+    gs = g.g(0.5, 0, conv=1e-9)
+    assert abs(gs[0, 0] - (0.5 - 1j * np.sqrt(4 - 0.25)) / 2) < 1e-3
+
+
+# --------------------------------------------------------------------------- #
+# Bethe lattice
+# --------------------------------------------------------------------------- #
+def _bethe_atom(name="Au"):
+    from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix, gen_neighbors, surfGBAt
+    here = os.path.join(os.path.dirname(__file__), "golden", name)
+    ne, Ed, Vd, Sd, H0 = read_bethe_params(here)
+    dirs = gen_neighbors(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.2, 0.0]))
+    Sl = [construct_sk_matrix(Sd, d) for d in dirs]
+    Vl = [construct_sk_matrix(Vd, d) for d in dirs]
+    return surfGBAt(H0, Sl, Vl, 1e-6), H0, Sl, Vl
+
+
+@pytest.mark.parametrize("name", ["Au", "Au2"])
+def test_bethe_raw_fixed_trip_count(engine, name):
+    at, H0, Sl, Vl = _bethe_atom(name)
+    at.force_iters = 25
+    for E in (-5.0, 0.7, -2.0 + 0.3j):
+        ref, _, _ = oracle.bethe_sigmaK(E, H0, Sl, Vl, 1e-6, force_iters=25)
+        assert rel_fro(at.sigmaK(E), ref) < 1e-10, (name, E)
+        ref9, _, _, _ = oracle.bethe_sigma_surface(E, H0, Sl, Vl, 1e-6, force_iters=25)
+        assert rel_fro(at.sigma(E), ref9) < 1e-10, (name, E)
+    cl = oracle.bethe_cluster_sigma_total(-5.0, H0, Sl, Vl, 1e-6, force_iters=25)
+    assert rel_fro(at.sigmaTot(-5.0), cl) < 1e-10
+
+
+def test_bethe_raw_free_running(engine):
+    at, H0, Sl, Vl = _bethe_atom()
+    E = np.array([-6.0, -5.0, -3.0, 1.0])
+    out = at.sigmaK(E)
+    its = at.last_iters.copy()
+    for k, e in enumerate(E):
+        ref, count, diff = oracle.bethe_sigmaK(e, H0, Sl, Vl, 1e-6)
+        assert abs(int(its[k]) - count) <= 1
+        assert rel_fro(out[k], ref) < 10 * 1e-5
+
+
+def _bethe_device(name, N=40):
+    from gaunegf_amd.surfGBethe import surfGB
+    # two contacts of 2 atoms x 9 orbitals at the ends of an N-orbital device; geometry:
+    # atoms on a line plus one in-plane neighbour each so that the surface normal is defined
+    coords = np.array([[0, 0, 0.0], [2.88, 0, 0], [1.44, 2.494, 0],
+                       [0, 0, 20.0], [2.88, 0, 20.0], [1.44, 2.494, 20.0],
+                       [1.44, 0.8, 10.0]])
+    n_atoms = len(coords)
+    orbMap = np.concatenate([np.full(9, a + 1) for a in range(6)] + [np.full(N - 54, 7)])
+    typ_one = np.array([0, 1001, 1002, 1003, 2001, 2002, 2003, 2004, 2005])
+    orbTyp = np.concatenate([typ_one] * 6 + [np.zeros(N - 54, dtype=int)])
+    return coords, orbMap, orbTyp
+
+
+@pytest.mark.parametrize("name", ["Au", "Au2"])
+def test_bethe_contact_assembly_and_integrals(engine, name):
+    from gaunegf_amd.surfGBethe import surfGB
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    N = 60
+    coords, orbMap, orbTyp = _bethe_device(name, N)
+    F, S = random_system(N, 77)
+    lat = os.path.join(os.path.dirname(__file__), "golden", name)
+    g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
+    g.force_iters = 30
+    Xi = g.Xi if g.Sdict['sss'] == 0 else None
+
+    class Ref:
+        def sigma(self, E, i, conv=None):
+            at = g.gList[i]
+            return oracle.bethe_contact_sigma(E, N, g.indsLists[i], g.nIndLists[i], at.H, at.Slist, at.Vlist,
+                                              1e-6, Xi=Xi, force_iters=30)
+        def sigmaTot(self, E, conv=None):
+            return self.sigma(E, 0) + self.sigma(E, 1)
+    ref = Ref()
+    for E in (-4.0, 0.5):
+        for i in (0, 1):
+            assert rel_fro(g.sigma(E, i), ref.sigma(E, i)) < 1e-9, (name, E, i)
+        assert rel_fro(g.sigmaTot(E), ref.sigmaTot(E)) < 1e-9
+    E, w = oracle.contour_grid(-8.0, 0.0, 18, 0.0)
+    assert rel_fro(GrInt(F, S, g, E, w), oracle.GrInt(F, S, ref, E, w)) < TOL
+    Eg, wg = oracle.bias_window_grid(-0.2, 0.2, 8, 300.0)
+    for ind in (None, 0, -1):
+        assert rel_fro(GrLessInt(F, S, g, Eg, wg, ind), oracle.GrLessInt(F, S, ref, Eg, wg, ind)) < TOL
+
+
+# --------------------------------------------------------------------------- #
+# density front-ends end to end, and full-size properties
+# --------------------------------------------------------------------------- #
+def test_density_front_ends(engine):
+    from gaunegf_amd.density import densityComplexN, densityRealN, densityGridN, densityComplex
+    F, S, g_dev, g_ref = _const_provider(40, 5)
+    P = densityComplexN(F, S, g_dev, -6.0, 0.1, 54, 300.0, showText=False)
+    E, w = oracle.contour_grid(-6.0, 0.1, 54, 300.0); Eb, wb = oracle.broadening_grid(0.1, 54, 300.0)
+    ref = np.imag(oracle.GrInt(F, S, g_ref, E, w) + oracle.GrInt(F, S, g_ref, Eb, wb)) / np.pi
+    assert rel_fro(P, ref) < TOL
+    Pr = densityRealN(F, S, g_dev, -50.0, -6.0, 16, 0.0, showText=False)
+    E, w = oracle.real_axis_grid(-50.0, -6.0, 16, 0.0)
+    assert rel_fro(Pr, -np.imag(oracle.GrInt(F, S, g_ref, E, w)) / np.pi) < TOL
+    Pg = densityGridN(F, S, g_dev, -0.2, 0.3, ind=-1, N=20, T=300.0, showText=False)
+    E, w = oracle.bias_window_grid(-0.2, 0.3, 20, 300.0)
+    assert rel_fro(Pg, oracle.GrLessInt(F, S, g_ref, E, w, -1) / (2 * np.pi)) < TOL
+    # adaptive contour: same level sequence as the oracle's driver -> same value
+    Pa = densityComplex(F, S, g_dev, -6.0, 0.1, tol=1e-5, T=0.0)
+    _, center, r = -6.0, (-6.0 + 0.1) / 2, (0.1 + 6.0) / 2
+
+    def cp(x, wq):
+        th = np.pi / 2 * (x + 1); z = center + r * np.exp(1j * th); dz = 1j * r * np.exp(1j * th)
+        return oracle.GrInt(F, S, g_ref, z, (np.pi / 2) * wq * dz * oracle.fermi(z, 0.1, 0.0))
+    assert rel_fro(Pa, np.imag(oracle.adaptive_ant(cp, tol=1e-5)) / np.pi) < 1e-7
+    # trace of P S counts electrons: positive and below N
+    ne = np.real(np.trace(P @ S))
+    assert 0 < ne < 40
+
+
+def test_full_size_properties_C2(engine):
+    """BASELINE config C2 (N=200, constant Sigma, 1000 energies): size-independent
+    properties instead of a 1000-point oracle run."""
+    from gaunegf_amd.integrate import GrInt, GrLessInt, GrBatch
+    N, M = 200, 1000
+    F, S, g_dev, g_ref = _const_provider(N, 2, nc=20)
+    E, w = oracle.real_axis_grid(-3.0, 3.0, M, 0.0)
+    rng = np.random.default_rng(0)
+    w1 = rng.standard_normal(M); w2 = rng.standard_normal(M)
+    a = GrInt(F, S, g_dev, E, w1); b = GrInt(F, S, g_dev, E, w2); c = GrInt(F, S, g_dev, E, w1 + 2 * w2)
+    assert rel_fro(c, a + 2 * b) < 1e-12                       # linearity in the weights
+    assert np.array_equal(a, GrInt(F, S, g_dev, E, w1))        # run-to-run bitwise reproducible
+    # split grid = whole grid (batching / accumulation order independence to rounding)
+    d = GrInt(F, S, g_dev, E[:333], w1[:333]) + GrInt(F, S, g_dev, E[333:], w1[333:])
+    assert rel_fro(d, a) < 1e-12
+    # residual of a sample of inverses: G (E S - F - Sigma) = I
+    idx = rng.choice(M, 12, replace=False)
+    G = GrBatch(F, S, g_dev, E[idx])
+    st = g_ref.sigmaTot(0.0)
+    for k, i in enumerate(idx):
+        A = E[i] * S - F - st
+        assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9
+        assert rel_fro(G[k], oracle.gr_point(st, E[i], F, S)) < TOL
+    # G Gamma G^H is Hermitian for a Hermitian Gamma and real weights
+    L = GrLessInt(F, S, g_dev, E[:200], np.abs(w1[:200]), -1)
+    assert rel_fro(L, L.conj().T) < 1e-12
+    # bounded oracle sample of the integral itself
+    sub = slice(0, M, 25)
+    assert rel_fro(GrInt(F, S, g_dev, E[sub], w[sub]), oracle.GrInt(F, S, g_ref, E[sub], w[sub])) < TOL

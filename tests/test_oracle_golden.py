@@ -1,0 +1,195 @@
+"""
+The oracle (numpy restatement, oracle/) against vectors produced by EXECUTING the
+reference's own numpy-only code (tests/golden/make_golden.py).  Bit-exact for the
+grid / weight bookkeeping; 1e-12 for floating-point linear algebra that the
+reference's tests compute with np.linalg.inv where the oracle follows the
+production path's solve(A, I).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import MockSigma, rel_fro
+
+
+def test_ant_points_bit_exact(golden_book):
+    for N in (2, 6, 18, 54, 100):
+        x, w = oracle.ant_points(N)
+        assert np.array_equal(x, golden_book[f"ant_x_{N}"])
+        assert np.array_equal(w, golden_book[f"ant_w_{N}"])
+
+
+def test_testant_values(golden_book):
+    # tests/testANT.py main loop: quadrature of exp(-x^2) level by level
+    got = [float(np.dot(oracle.ant_points(N)[1], np.exp(-oracle.ant_points(N)[0] ** 2)))
+           for N in (2, 6, 18, 54, 162, 486)]
+    assert np.array_equal(np.array(got), golden_book["testant_direct"])
+    # the numbers quoted in SURVEY.md section 8c
+    assert abs(got[0] - 0.567305308152) < 1e-12 and abs(got[3] - 1.493648265625) < 1e-12
+
+
+def test_fermi_bit_exact(golden_book):
+    g = golden_book
+    assert np.array_equal(np.asarray(oracle.fermi(g["fermi_E_real"], 0.3, 0)), g["fermi_T0_real"])
+    assert np.array_equal(np.asarray(oracle.fermi(g["fermi_E_cplx"], 0.3, 0)), g["fermi_T0_cplx"])
+    assert np.array_equal(oracle.fermi(g["fermi_E_real"], 0.3, 300.0), g["fermi_T300_real"])
+    assert np.array_equal(oracle.fermi(g["fermi_E_cplx"], 0.3, 300.0), g["fermi_T300_cplx"])
+
+
+@pytest.mark.parametrize("tag,args", [
+    ("realN_T0", (-3.0, 0.3, 24, 0.0)), ("realN_T300", (-3.0, 0.3, 17, 300.0))])
+def test_real_axis_grid(golden_book, tag, args):
+    E, w = oracle.real_axis_grid(*args)
+    assert np.array_equal(E, golden_book[f"{tag}_c0_E"])
+    assert np.array_equal(w, golden_book[f"{tag}_c0_w"])
+
+
+@pytest.mark.parametrize("tag,args,ind", [
+    ("gridN_T0_fwd", (-0.25, 0.25, 16, 0.0), -1),
+    ("gridN_T300_rev", (0.25, -0.25, 20, 300.0), 0),
+    ("gridN_T300_none", (-0.1, 0.4, 9, 300.0), -99)])
+def test_bias_window_grid(golden_book, tag, args, ind):
+    E, w = oracle.bias_window_grid(*args)
+    assert np.array_equal(E, golden_book[f"{tag}_c0_E"])
+    assert np.array_equal(w, golden_book[f"{tag}_c0_w"])
+    assert int(golden_book[f"{tag}_c0_ind"]) == ind
+    assert str(golden_book[f"{tag}_c0_name"]) == "GrLessInt"
+
+
+@pytest.mark.parametrize("meth", ["ant", "legendre", "chebyshev", "midpoint"])
+def test_contour_grid(golden_book, meth):
+    E, w = oracle.contour_grid(-5.0, 0.3, 18, 0.0, meth)
+    assert np.array_equal(E, golden_book[f"cplxN_T0_{meth}_c0_E"])
+    assert np.array_equal(w, golden_book[f"cplxN_T0_{meth}_c0_w"])
+    assert int(golden_book[f"cplxN_T0_{meth}_ncalls"]) == 1
+    E, w = oracle.contour_grid(-5.0, 0.3, 32, 300.0, meth)
+    assert np.array_equal(E, golden_book[f"cplxN_T300_{meth}_c0_E"])
+    assert np.array_equal(w, golden_book[f"cplxN_T300_{meth}_c0_w"])
+    Eb, wb = oracle.broadening_grid(0.3, 32, 300.0, meth)
+    assert int(golden_book[f"cplxN_T300_{meth}_ncalls"]) == 2
+    assert np.array_equal(Eb, golden_book[f"cplxN_T300_{meth}_c1_E"])
+    assert np.array_equal(wb, golden_book[f"cplxN_T300_{meth}_c1_w"])
+
+
+def test_adaptive_levels(golden_book):
+    # the level sequence the reference's adaptive driver sends to GrInt (new nodes only)
+    g = golden_book
+    poles = np.array([-0.7 - 0.05j, 0.1 - 0.2j, 0.6 - 0.01j])
+    Emin, mu, T = -5.0, 0.3, 0.0
+    Emax = mu - 10 * oracle.kB * T
+    center = (Emin + Emax) / 2
+    r = (Emax - Emin) / 2
+    rec = []
+
+    def computePoint(x, w):
+        theta = np.pi / 2 * (x + 1)
+        z = center + r * np.exp(1j * theta)
+        dz = 1j * r * np.exp(1j * theta)
+        weights = (np.pi / 2) * w * dz * oracle.fermi(z, mu, T)
+        rec.append((z, weights))
+        acc = np.zeros((3, 3), dtype=complex)
+        for E, ww in zip(z, weights):
+            acc += ww * np.diag(1.0 / (E - poles))
+        return acc
+
+    res = oracle.adaptive_ant(computePoint, tol=1e-6)
+    n = int(g["cplx_adapt_T0_ncalls"])
+    assert len(rec) == n
+    for i in range(n):
+        assert np.array_equal(rec[i][0], g[f"cplx_adapt_T0_c{i}_E"])
+        assert np.array_equal(rec[i][1], g[f"cplx_adapt_T0_c{i}_w"])
+    assert np.array_equal((1 + 0j) * np.imag(res) / np.pi, g["cplx_adapt_T0_result"])
+
+
+def test_form_sigma(golden_book):
+    g = golden_book
+    S = g["formsigma_S"]
+    assert np.array_equal(oracle.form_sigma([0, 1], -0.1j, 6, S), g["formsigma_scalar"])
+    assert np.array_equal(oracle.form_sigma([4, 5], g["formsigma_Vm"], 6, S), g["formsigma_matrix"])
+    assert np.array_equal(oracle.form_sigma([2], -0.05j, 6), g["formsigma_noS"])
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("cur_T0_pos", dict(fermi_E=0.1, qV=0.05, T=0.0, dE=0.001)),
+    ("cur_T0_neg", dict(fermi_E=0.1, qV=-0.05, T=0.0, dE=0.001)),
+    ("cur_T300_pos", dict(fermi_E=-0.2, qV=0.1, T=300.0, dE=0.002))])
+def test_current_grid_and_quadrature(golden_book, tag, kw):
+    grid, muL, muR = oracle.current_grid(**kw)
+    assert np.array_equal(grid, golden_book[f"{tag}_grid"])
+    T = 1.0 / (1.0 + (grid - 0.05) ** 2)
+    cur = oracle.current_from_transmission(T, grid, muL, muR, kw["T"], 'r')
+    assert cur == float(golden_book[f"{tag}_value"])
+
+
+@pytest.mark.parametrize("size", [12, 40])
+def test_gr_gless_vs_reference_numpy_loops(golden_num, size):
+    g = golden_num
+    F, S = g[f"cc{size}_F"], g[f"cc{size}_S"]
+    prov = MockSigma(g[f"cc{size}_sigma_base"], [g[f"cc{size}_sigma_c0"], g[f"cc{size}_sigma_c1"]])
+    E, w = g[f"cc{size}_E"], g[f"cc{size}_w"]
+    assert rel_fro(oracle.GrInt(F, S, prov, E, w), g[f"cc{size}_gr"]) < 1e-12
+    assert rel_fro(oracle.GrLessInt(F, S, prov, E, w, None), g[f"cc{size}_gless_none"]) < 1e-12
+    assert rel_fro(oracle.GrLessInt(F, S, prov, E, w, 0), g[f"cc{size}_gless_0"]) < 1e-12
+    assert rel_fro(oracle.GrLessInt(F, S, prov, E, w, 1), g[f"cc{size}_gless_1"]) < 1e-12
+
+
+@pytest.mark.parametrize("size", [5, 10, 20])
+def test_chain_fixed_point_vs_reference_manual_iteration(golden_num, size):
+    # tests/test_surface_green_jit.py:47-68 starts from zeros, eta=1e-4, conv=1e-8, 500 sweeps max
+    g = golden_num
+    al, Sa, be, Sb = (g[f"sg{size}_{k}"] for k in ("alpha", "Salpha", "beta", "Sbeta"))
+    for ie, E in enumerate(g["sg_energies"]):
+        gi, count, diff = oracle.chain1d_g(E, al, Sa, be, Sb, 1e-4, conv=1e-8, relFactor=0.1,
+                                           max_iter=500, g_init=np.zeros((size, size), dtype=complex))
+        assert count == int(g[f"sg{size}_e{ie}_iters"])
+        assert (diff <= 1e-8) == bool(g[f"sg{size}_e{ie}_conv"])
+        assert np.max(np.abs(gi - g[f"sg{size}_e{ie}_g"])) < 1e-10      # the reference's own bar (:123)
+
+
+def test_chain_sigma_vs_reference_benchmark(golden_num):
+    # tests/benchmark_sigma_parallelization.py:92-119 (tau = beta, Stau = Sbeta, zero start)
+    g = golden_num
+    al, Sa, be, Sb = (g[f"bs8_{k}"] for k in ("alpha", "Salpha", "beta", "Sbeta"))
+    for ie, E in enumerate(g["bs8_energies"]):
+        gi, count, diff = oracle.chain1d_g(E, al, Sa, be, Sb, 1e-3, conv=1e-5, relFactor=0.1,
+                                           max_iter=1000, g_init=np.zeros((8, 8), dtype=complex))
+        sig = oracle.chain1d_sigma_block(E, be, Sb, gi)
+        assert count == int(g[f"bs8_e{ie}_iters"])
+        assert rel_fro(sig, g[f"bs8_e{ie}_sigma"]) < 1e-10
+
+
+def test_transmission_dos_vs_reference_inline_numpy(golden_num):
+    g = golden_num
+    F, S, st, G1, G2 = (g[f"rts24_{k}"] for k in ("F", "S", "sigma", "G1", "G2"))
+    for E, T, D in zip(g["rts24_energies"], g["rts24_T"], g["rts24_dos"]):
+        assert abs(oracle.transmission_restricted(E, F, S, st, G1, G2) - T) < 1e-8 * max(1, abs(T))
+        assert abs(oracle.dos_at_energy(E, F, S, st) - D) < 1e-8 * max(1, abs(D))
+        tot, site = oracle.dos_kernel(E, F, S, st)
+        assert abs(tot - D) < 1e-8 * max(1, abs(D))
+
+
+def test_bethe_invariants():
+    # no reference output exists for the Bethe loop (needs jax): physical invariants only.
+    # Retarded convention of this code path is E - i*eta, so Im(sigma) >= 0 on the diagonal.
+    from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix, gen_neighbors
+    import os
+    ref = os.path.join(os.path.dirname(__file__), "golden", "Au")
+    ne, Ed, Vd, Sd, H0 = read_bethe_params(ref)
+    dirs = gen_neighbors(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    Sl = [construct_sk_matrix(Sd, d) for d in dirs]
+    Vl = [construct_sk_matrix(Vd, d) for d in dirs]
+    sig, count, diff = oracle.bethe_sigmaK(-5.0, H0, Sl, Vl, 1e-6, conv=1e-9)
+    assert count < 1000 and diff <= 1e-9
+    # opposite directions are related by inversion: same spectrum of the 9x9 blocks
+    for k in range(6):
+        ev1 = np.sort_complex(np.linalg.eigvals(sig[k]))
+        ev2 = np.sort_complex(np.linalg.eigvals(sig[k + 6]))
+        assert np.allclose(ev1, ev2, atol=1e-6)
+    s9, c2, d2, _ = oracle.bethe_sigma_surface(-5.0, H0, Sl, Vl, 1e-6, conv=1e-9)
+    assert c2 < 1000 and d2 <= 1e-9
+    # the converged surface solution satisfies its own Dyson equation
+    z = -5.0 - 1e-6j
+    gs = np.linalg.inv(z * np.eye(9) - H0 - np.sum(s9, axis=0))
+    for k in (0, 1, 2, 6, 7, 8):
+        B = z * Sl[k] - Vl[k]
+        assert rel_fro(s9[k], B @ gs @ B.conj().T) < 1e-6
