@@ -184,8 +184,12 @@ void run_inverse(negf_ctx* c, int nb, int* info)
     int algo = c->inverse_algo;
     if (algo == 0) algo = inverse_blocked_supported(c->n) ? 2 : 1;
     if (algo == 2 && !inverse_blocked_supported(c->n)) algo = 1;
-    if (algo == 2) launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_ipiv, info);
+    bool in_b = false;
+    if (algo == 2) in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, info);
     else launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info);
+    c->G = in_b ? c->d_T1 : c->d_A;
+    c->W1 = in_b ? c->d_A : c->d_T1;
+    c->W2 = c->d_T2;
 }
 
 // Sigma blocks of a block provider for energies E[0..nb) -> c->d_blk
@@ -256,7 +260,7 @@ int run_assemble(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cplx* E)
 // dense Gamma_b = i (Sigma_c - Sigma_c^H) for batch [m0, m0+nb) into `out`
 // (stride n*n); returns the batch stride to use (0 when one matrix serves all).
 int run_gamma(negf_ctx* c, SigmaProvider* p, int contact /* -1 total */, int m0, int nb, cplx* out,
-              const cplx** gptr, size_t* stride_out)
+              cplx* scratch, const cplx** gptr, size_t* stride_out)
 {
     const size_t n2 = (size_t)c->n * c->n;
     *gptr = out;
@@ -292,15 +296,15 @@ int run_gamma(negf_ctx* c, SigmaProvider* p, int contact /* -1 total */, int m0,
         launch_scatter_blocks(c->stream, c->n, nb, c->d_blk, p->blk_stride, p->n_contacts, p->d_nc,
                               p->d_blk_off, p->d_inds_off, p->d_inds, contact, out);
         if (p->d_xi) {
-            // Xi sig Xi through T2 as scratch; caller passes out != T2
-            launch_zgemm(c->stream, c->n, c->n, c->n, nb, p->d_xi, c->n, 0, out, c->n, n2, 0, c->d_T2,
+            // Xi sig Xi through the scratch area
+            launch_zgemm(c->stream, c->n, c->n, c->n, nb, p->d_xi, c->n, 0, out, c->n, n2, 0, scratch,
                          c->n, n2);
-            launch_zgemm(c->stream, c->n, c->n, c->n, nb, c->d_T2, c->n, n2, p->d_xi, c->n, 0, 0, out,
+            launch_zgemm(c->stream, c->n, c->n, c->n, nb, scratch, c->n, n2, p->d_xi, c->n, 0, 0, out,
                          c->n, n2);
         }
-        // in place: gamma kernel reads s[t] and s[transpose]; use T2 as the target then copy back
-        launch_gamma_dense(c->stream, c->n, nb, out, n2, c->d_T2);
-        (void)hipMemcpyAsync(out, c->d_T2, n2 * nb * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream);
+        // the gamma kernel reads s[t] and s[transpose]: not in place -> via scratch
+        launch_gamma_dense(c->stream, c->n, nb, out, n2, scratch);
+        (void)hipMemcpyAsync(out, scratch, n2 * nb * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream);
         *stride_out = n2;
         return NEGF_OK;
     }
@@ -629,7 +633,7 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
         ProfScope ps(c, "accumulate");
-        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->d_A, out);
+        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out);
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
@@ -660,15 +664,15 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
         run_inverse(c, nb, c->d_info + m0);
         size_t gs = 0;
         const cplx* gam = nullptr;
-        { ProfScope ps(c, "gamma"); if ((rc = run_gamma(c, p, contact, m0, nb, c->d_T1, &gam, &gs))) return rc; }
+        { ProfScope ps(c, "gamma"); if ((rc = run_gamma(c, p, contact, m0, nb, c->W1, c->W2, &gam, &gs))) return rc; }
         {
             ProfScope ps(c, "zgemm");
-            // T2 = G Gamma ; T1 = T2 G^H   (integrate.py:81)
-            launch_zgemm(c->stream, n, n, n, nb, c->d_A, n, n2, gam, n, gs, 0, c->d_T2, n, n2);
-            launch_zgemm(c->stream, n, n, n, nb, c->d_T2, n, n2, c->d_A, n, n2, 1, c->d_T1, n, n2);
+            // W2 = G Gamma ; W1 = W2 G^H   (integrate.py:81)
+            launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, gam, n, gs, 0, c->W2, n, n2);
+            launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, 1, c->W1, n, n2);
         }
         ProfScope ps(c, "accumulate");
-        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->d_T1, out);
+        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out);
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
@@ -701,17 +705,17 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
         const int nb = std::min(half, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
-        cplx* G = c->d_A;
+        cplx* G = c->G;
         const cplx* gamL = nullptr;           // [nb] (or one shared matrix)
         const cplx* gamR = nullptr;
-        cplx* X = c->d_T2;                    // [nb]
-        cplx* Y = c->d_A + n2 * half;         // [nb]
+        cplx* X = c->W2;                      // [nb]
+        cplx* Y = c->G + n2 * half;           // [nb] upper half of the buffer holding G (unused by this sweep)
         size_t gsL = 0, gsR = 0;
         {
             ProfScope ps(c, "gamma");
-            // run_gamma uses T2 as scratch for block providers -> build both before X is live
-            if ((rc = run_gamma(c, p, cL, m0, nb, c->d_T1, &gamL, &gsL))) return rc;
-            if ((rc = run_gamma(c, p, cR, m0, nb, c->d_T1 + n2 * half, &gamR, &gsR))) return rc;
+            // W2 doubles as run_gamma's scratch -> build both Gammas before X is live
+            if ((rc = run_gamma(c, p, cL, m0, nb, c->W1, c->W2, &gamL, &gsL))) return rc;
+            if ((rc = run_gamma(c, p, cR, m0, nb, c->W1 + n2 * half, c->W2, &gamR, &gsR))) return rc;
         }
         if (spin_mode == NEGF_SPIN_RESTRICTED) {
             {
@@ -816,7 +820,7 @@ int negf_gr_batch(negf_ctx* c, int handle, int m, const double* E, double* G_out
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
-        if ((rc = download(c, reinterpret_cast<cplx*>(G_out) + n2 * m0, c->d_A, n2 * nb))) return rc;
+        if ((rc = download(c, reinterpret_cast<cplx*>(G_out) + n2 * m0, c->G, n2 * nb))) return rc;
     }
     c->last_m = m;
     return reduce_info(c, m, info);
@@ -862,7 +866,7 @@ int negf_dos(negf_ctx* c, int handle, int m, const double* E, double* dos_total,
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
-        { ProfScope ps(c, "trace"); launch_dos(c->stream, c->n, nb, c->d_A, c->d_scal + m0, dos_site ? c->d_site : nullptr); }
+        { ProfScope ps(c, "trace"); launch_dos(c->stream, c->n, nb, c->G, c->d_scal + m0, dos_site ? c->d_site : nullptr); }
         if (dos_site && (rc = download(c, dos_site + (size_t)m0 * c->n, c->d_site, (size_t)nb * c->n))) return rc;
     }
     if ((rc = download(c, dos_total, c->d_scal, (size_t)m))) return rc;

@@ -118,6 +118,9 @@ struct negf_ctx {
     cplx* d_A = nullptr;           // [batch][n*n]   assembled matrix -> inverse in place
     cplx* d_T1 = nullptr;          // [batch][n*n]   temp products
     cplx* d_T2 = nullptr;          // [batch][n*n]
+    cplx* G = nullptr;             // where the last inverse left its result (d_A or d_T1)
+    cplx* W1 = nullptr;            // the other of (d_A, d_T1): free work area after the inverse
+    cplx* W2 = nullptr;            // = d_T2
     cplx* d_blk = nullptr;         // [batch][blk_stride] contact blocks of Sigma(E)
     int blk_cap = 0;
     cplx* d_scratch = nullptr;     // per-workgroup scratch of the Sigma kernels
@@ -166,7 +169,9 @@ void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S
 
 // in-place inverse of nb matrices; info[b] = 0 or 1-based column of a zero pivot
 void launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
-void launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, int* ipiv, int* info);
+// out-of-place ping-pong between A and B (both [nb][stride]); returns true when the
+// inverses end up in B, false when in A
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info);
 bool inverse_blocked_supported(int n);
 
 // acc += sum_b w[b] * X[b]   (fixed order b = 0..nb-1, deterministic)

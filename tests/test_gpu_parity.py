@@ -175,14 +175,30 @@ def test_transmission_front_end(engine, N, tmp_path):
     assert np.allclose(site.sum(axis=1), tot, rtol=1e-9)
     dref = np.array([oracle.dos_kernel(e, F, S, st)[0] for e in E])
     assert np.max(np.abs(tot - dref) / np.maximum(1.0, np.abs(dref))) < TOL
-    # current: |I(+V)| == |I(-V)| (rtol 1e-6, :549), zero bias -> 0 (:520), value vs oracle
+    # current: zero bias -> 0 (:520), value vs oracle
     Ip = calculate_current(F, S, sc, 0.0, 0.1, T=0.0, dE=0.01)
-    Im = calculate_current(F, S, sc, 0.0, -0.1, T=0.0, dE=0.01)
-    assert abs(abs(Ip) - abs(Im)) <= 1e-6 * abs(Ip)
     assert calculate_current(F, S, sc, 0.0, 0.0) == 0.0
     grid, muL, muR = oracle.current_grid(0.0, 0.1, 0.0, 0.01)
     Tg = np.array([oracle.transmission_restricted(e, F, S, st, g1, g2) for e in grid])
     assert abs(Ip - oracle.current_from_transmission(Tg, grid, muL, muR, 0.0, 'r')) < 1e-8 * abs(Ip)
+
+
+def test_wire_current_symmetry(engine, golden_num):
+    """The reference's tight-binding wire (tests/test_transport_checkpointing.py:22-58:
+    t=-1, eps=0, S=I) with diagonal contacts is particle-hole symmetric, so
+    |I(+V)| == |I(-V)| (rtol 1e-6, :549) and T >= 0 (:331)."""
+    from gaunegf_amd.transport import SigmaCalculator, calculate_current, calculate_transmission
+    F = np.real(golden_num["wire20_F"]); S = np.real(golden_num["wire20_S"])
+    N = F.shape[0]
+    inds, s1, s2 = const_sigma_pair(N, S, N // 2, gamma=0.1)       # contacts = N/2 sites each (:623)
+    sc = SigmaCalculator(s1, s2)
+    for T in (0.0, 300.0):
+        Ip = calculate_current(F, S, sc, 0.0, 0.1, T=T, dE=0.005)
+        Im = calculate_current(F, S, sc, 0.0, -0.1, T=T, dE=0.005)
+        assert Ip > 0 and abs(abs(Ip) - abs(Im)) <= 1e-6 * abs(Ip)
+    Tr = calculate_transmission(F, S, sc, np.linspace(-2.5, 2.5, 41))
+    assert np.all(Tr >= 0) and np.all(np.isfinite(Tr))
+    assert np.allclose(Tr, Tr[::-1], rtol=1e-9)
 
 
 @pytest.mark.parametrize("spin", ["u", "g"])
