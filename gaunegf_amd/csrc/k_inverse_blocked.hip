@@ -1,5 +1,5 @@
-// Blocked in-place-style Gauss-Jordan inversion with partial pivoting, FP64 MFMA
-// trailing updates, one workgroup (512 threads, 8 waves) per matrix.   gfx950.
+// Blocked Gauss-Jordan inversion with partial pivoting, FP64 MFMA trailing updates,
+// one workgroup (512 threads, 8 waves) per matrix.   gfx950 / MI355X.
 //
 // Replaces G = solve(E S - F - Sigma, I)  (gauNEGF/integrate.py:71, utils.py:52-54,
 // transport.py:154,163,186) for every energy point of the grid.
@@ -9,21 +9,25 @@
 //      (S complex128 per strip).  kw unblocked Gauss-Jordan column steps with
 //      partial pivoting (LAPACK izamax rule |re|+|im|, first maximum) run on the
 //      strips; only the pivot row (NB values), the pivot column (n values) and the
-//      arg-max partials go through LDS.  Rows are never moved: each strip carries
-//      its logical position `pos`; the interchange sequence ipiv[] is recorded.
-//      After the kw steps the panel equals the block column of the elementary
-//      transform  M_K = [ -A01 A11^-1 ; A11^-1 ; -A21 A11^-1 ]  (rows in permuted order).
+//      per-wave arg-max partials go through LDS (two barriers per column step; the
+//      pivot search of step j+1 is fused into the update of step j; the wave-level
+//      arg-max uses DPP lane moves, not LDS permutes).  Rows are never moved: each
+//      strip carries its logical position `pos`; the interchange sequence ipiv[] is
+//      recorded.  After the kw steps the panel equals the block column of the
+//      elementary transform  M_K = [ -A01 A11^-1 ; A11^-1 ; -A21 A11^-1 ].
 //   2. The strips are written to LDS as P (logical row order) together with the row
 //      map src[] (new logical row i <- old row src[i]).
 //   3. TRAILING UPDATE on the matrix cores, OUT OF PLACE (ping-pong buffers), which
 //      folds the row interchanges into the tile loads and removes every in-place
 //      hazard:     new[i][J] = (i in K ? 0 : old[src[i]][J]) + P[i][:] * Q[:][J],
 //      Q[k][J] = old[src[k0+k]][J];   new[:, K] = P.
-//      A 16x16 complex tile is 4 real v_mfma_f64_16x16x4_f64 chains per 4-deep k-step
-//      (Cr += Pr Qr; Cr += (-Pi) Qi; Ci += Pr Qi; Ci += Pi Qr).
+//      Work item = (column tile J, half of the row tiles): the wave loads the Q
+//      fragments of J once into registers and sweeps its row tiles, prefetching the
+//      next C tile while the current 16x16 tile runs its 4*NB/4 MFMAs
+//      (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
 //   4. After the last panel the column interchanges are undone (reverse order) while
 //      copying to the other buffer.
-// Flops: 8 n^3 per matrix (complex MAC = 8), the same as LU + triangular inversion;
+// Flops: 8 n^3 per matrix (complex MAC = 8), the LU + triangular-inversion optimum;
 // every step updates the full n x n matrix, so the MFMA work per step is uniform.
 //
 // Data layout: row-major complex128 (interleaved), ld = n.  A lane fetches one
@@ -46,14 +50,158 @@ struct GjCfg {
     static constexpr int PITCH = NB + 1;           // LDS row pitch of P in complex (odd -> conflict free)
 };
 
-struct RedSlot { double v; int pos; int phys; };
+struct RedSlot { double v; int key; int pad; };
+
+// ---- wave-level arg-max of (v, key): larger v wins, ties -> smaller key -------------
+// DPP lane moves inside each row of 16 lanes (xor 1, xor 2, half mirror, mirror), then
+// the four row results are combined through v_readlane.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ void dpp_step(double& v, int& key)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    const int okey = __builtin_amdgcn_update_dpp(key, key, CTRL, 0xF, 0xF, false);
+    const double ov = __hiloint2double(ohi, olo);
+    const bool take = (ov > v) | ((ov == v) & (okey < key));
+    v = take ? ov : v; key = take ? okey : key;
+}
+
+__device__ __forceinline__ void wave_argmax(double& v, int& key)
+{
+    dpp_step<0xB1>(v, key);      // quad_perm [1,0,3,2]
+    dpp_step<0x4E>(v, key);      // quad_perm [2,3,0,1]
+    dpp_step<0x141>(v, key);     // row_half_mirror
+    dpp_step<0x140>(v, key);     // row_mirror  -> every lane of a row holds the row result
+    double bv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
+                                 __builtin_amdgcn_readlane(__double2loint(v), 0));
+    int bk = __builtin_amdgcn_readlane(key, 0);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), r * 16);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), r * 16);
+        const int k = __builtin_amdgcn_readlane(key, r * 16);
+        const double ov = __hiloint2double(hi, lo);
+        const bool take = (ov > bv) | ((ov == bv) & (k < bk));
+        bv = take ? ov : bv; bk = take ? k : bk;
+    }
+    v = bv; key = bk;
+}
+
+constexpr int KEY_NONE = 0x7fffffff;
+__device__ __forceinline__ int make_key(int pos, int phys) { return (pos << 12) | phys; }
+
+// ---- one Gauss-Jordan column step on the register strips, J known at compile time ----
+template <int NB, int CPR, int RPT>
+struct PanelCtx {
+    cplx (&a)[RPT][NB / CPR];
+    int (&pos)[RPT];
+    cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh; int* ipiv;
+    int n, k0, kw, tid, lane, wave, h, tr;
+};
+
+template <int NB, int CPR, int RPT, int J>
+struct PanelSteps {
+    static __device__ __forceinline__ void run(PanelCtx<NB, CPR, RPT>& x)
+    {
+        using C = GjCfg<NB, CPR, RPT>;
+        constexpr int S = C::S, TPR = C::TPR;
+        constexpr int hj = J / S, sj = J % S;
+        if (J < x.kw) {                                     // uniform branch
+            const int c = x.k0 + J;
+            RedSlot* red = x.red + (J & 1) * GJB_WAVES;
+            // (1) combine the per-wave partials published by the previous step
+            double wv = red[0].v; int wkey = red[0].key;
+#pragma unroll
+            for (int w = 1; w < GJB_WAVES; ++w) {
+                const double ov = red[w].v; const int ok = red[w].key;
+                const bool take = (ov > wv) | ((ov == wv) & (ok < wkey));
+                wv = take ? ov : wv; wkey = take ? ok : wkey;
+            }
+            int p, pphys;
+            if (wkey != KEY_NONE) { p = wkey >> 12; pphys = wkey & 0xFFF; }
+            else { p = c; pphys = -1; }                     // NaN column: keep the diagonal row
+            if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // exactly singular / NaN
+            // (2) publish the unscaled pivot row, 1/pivot and the pivot column
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = x.tr + q * TPR;
+                const bool is_piv = (pphys >= 0) ? (r == pphys) : (x.pos[q] == c && r < x.n);
+                if (is_piv) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) x.rowbuf[x.h * S + s] = x.a[q][s];
+                    if (x.h == hj) {
+                        // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
+                        // overflow range for these matrices)
+                        const cplx pv = x.a[q][sj];
+                        const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+                        *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
+                    }
+                }
+                if (x.h == hj) x.colbuf[r] = x.a[q][sj];
+            }
+            if (x.tid == 0) x.ipiv[c] = p;
+            __syncthreads();
+            // (3) rank-1 update of every strip.  One batch of LDS reads (pivot row part, 1/pivot,
+            //     own pivot-column entries), then pure register arithmetic.  The pivot row and
+            //     the other rows share one form  a <- base + coef * rowbuf:
+            //        pivot row : base = 0, coef = 1/pivot        (row / pivot)
+            //        other rows: base = a, coef = -(f / pivot)   (row - f/pivot * pivot row)
+            //     and the pivot-column entry becomes coef in both cases.
+            const cplx ip = *x.piv_ip;
+            cplx rb[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) rb[s] = x.rowbuf[x.h * S + s];
+            cplx fcol[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) fcol[q] = x.colbuf[x.tr + q * TPR];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = x.tr + q * TPR;
+                const bool is_piv = (pphys >= 0) ? (r == pphys) : (x.pos[q] == c && r < x.n);
+                const cplx nfm = cneg(cmul(fcol[q], ip));
+                const cplx coef = is_piv ? ip : nfm;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s];
+                    x.a[q][s] = cfma(base, coef, rb[s]);
+                }
+                if (x.h == hj) x.a[q][sj] = coef;
+                x.pos[q] = is_piv ? c : (x.pos[q] == c ? p : x.pos[q]);
+            }
+            // (4) pivot search for column J+1 on the freshly updated strips
+            if constexpr (J + 1 < NB) {
+                constexpr int hn = (J + 1) / S, sn = (J + 1) % S;
+                double bv = -1.0; int bkey = KEY_NONE;
+                if (x.h == hn && J + 1 < x.kw) {
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const int r = x.tr + q * TPR;
+                        if (r < x.n && x.pos[q] >= c + 1) {
+                            const double v = cabs1(x.a[q][sn]);
+                            const int key = make_key(x.pos[q], r);
+                            if (v > bv || (v == bv && key < bkey)) { bv = v; bkey = key; }
+                        }
+                    }
+                }
+                wave_argmax(bv, bkey);
+                RedSlot* rn = x.red + ((J + 1) & 1) * GJB_WAVES;
+                if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
+            }
+            __syncthreads();
+            if constexpr (J + 1 < NB) PanelSteps<NB, CPR, RPT, J + 1>::run(x);
+        }
+    }
+};
 
 template <int NB, int CPR, int RPT>
 __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
-    int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info)
+    int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
+    int dbg /* ablation switches, 0 in production: 1 = no pivot steps, 2 = no MFMA, 4 = no tile loads */)
 {
     using C = GjCfg<NB, CPR, RPT>;
     constexpr int S = C::S, TPR = C::TPR, PITCH = C::PITCH;
+    constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int rows16 = (n + 15) & ~15;
@@ -63,7 +211,7 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     int* src = reinterpret_cast<int*>(colbuf + C::ROWS);         // [rows16] new row i <- old row src[i]
     int* ipiv = src + rows16;                                    // [n]
     int* colsrc = ipiv + rows16;                                 // [rows16]
-    __shared__ RedSlot red[GJB_WAVES];
+    __shared__ RedSlot red[2][GJB_WAVES];
     __shared__ cplx piv_ip;
     __shared__ int bad_sh;
 
@@ -83,95 +231,44 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int kw = min(NB, n - k0);
         __syncthreads();
-        // ---------------- panel: global (coalesced) -> LDS -> register strips
-        for (int t = tid; t < n * NB; t += GJB_THREADS) {
-            const int r = t / NB, j = t - r * NB;
-            P[(size_t)r * PITCH + j] = (j < kw) ? cur[(size_t)r * n + k0 + j] : cmake(0.0, 0.0);
-        }
-        __syncthreads();
+        // ---------------- panel: global -> register strips.  Every thread fetches its own strip
+        // (S independent 16-byte loads issued back to back: one memory latency per panel)
         cplx a[RPT][S];
         int pos[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int r = tr + q * TPR;
             pos[q] = r;
+            const cplx* g = cur + (size_t)(r < n ? r : 0) * n + k0 + h * S;
 #pragma unroll
-            for (int s = 0; s < S; ++s) a[q][s] = (r < n) ? P[(size_t)r * PITCH + h * S + s] : cmake(0.0, 0.0);
+            for (int s = 0; s < S; ++s)
+                a[q][s] = (r < n && h * S + s < kw) ? g[s] : cmake(0.0, 0.0);
         }
-        // ---------------- kw Gauss-Jordan column steps on the register strips
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (j < kw) {                                   // uniform branch
-                const int c = k0 + j;
-                const int hj = j / S, sj = j % S;           // compile-time: j is unrolled
-                // (1) arg-max of |.|_1 over logical rows >= c
-                double bv = -1.0; int bpos = 0x7fffffff, bphys = -1;
-                if (h == hj) {
-#pragma unroll
-                    for (int q = 0; q < RPT; ++q) {
-                        const int r = tr + q * TPR;
-                        if (r < n && pos[q] >= c) {
-                            const double v = cabs1(a[q][sj]);
-                            if (v > bv || (v == bv && pos[q] < bpos)) { bv = v; bpos = pos[q]; bphys = r; }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ov = __shfl_down(bv, off, 64);
-                    const int op = __shfl_down(bpos, off, 64);
-                    const int oph = __shfl_down(bphys, off, 64);
-                    if (ov > bv || (ov == bv && op < bpos)) { bv = ov; bpos = op; bphys = oph; }
-                }
-                __syncthreads();                            // previous step's LDS reads are done
-                if (lane == 0) { red[wave].v = bv; red[wave].pos = bpos; red[wave].phys = bphys; }
-                __syncthreads();
-                double wv = red[0].v; int p = red[0].pos, pphys = red[0].phys;
-#pragma unroll
-                for (int w = 1; w < GJB_WAVES; ++w) {
-                    const double ov = red[w].v; const int op = red[w].pos;
-                    if (ov > wv || (ov == wv && op < p)) { wv = ov; p = op; pphys = red[w].phys; }
-                }
-                if (!(wv > 0.0)) {                          // exactly singular / NaN column
-                    if (tid == 0 && bad_sh == 0) bad_sh = c + 1;
-                    if (pphys < 0) p = c;                   // NaN everywhere: keep the diagonal row
-                }
-                // (2) publish the unscaled pivot row, 1/pivot and the pivot column
+        // ---------------- pivot search for the first column of the panel
+        if (!(dbg & 1)) {
+            double bv = -1.0; int bkey = KEY_NONE;
+            if (h == 0) {
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) {
                     const int r = tr + q * TPR;
-                    const bool is_piv = (pphys >= 0) ? (r == pphys) : (pos[q] == c && r < n);
-                    if (is_piv) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) rowbuf[h * S + s] = a[q][s];
-                        if (h == hj) piv_ip = crecip(a[q][sj]);
-                    }
-                    if (h == hj) colbuf[r] = a[q][sj];
-                }
-                if (tid == 0) ipiv[c] = p;
-                __syncthreads();
-                // (3) rank-1 update of every strip
-                const cplx ip = piv_ip;
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int r = tr + q * TPR;
-                    const bool is_piv = (pphys >= 0) ? (r == pphys) : (pos[q] == c && r < n);
-                    if (is_piv) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) a[q][s] = cmul(rowbuf[h * S + s], ip);
-                        if (h == hj) a[q][sj] = ip;
-                        pos[q] = c;
-                    } else {
-                        const cplx fm = cmul(colbuf[r], ip);            // multiplier f / pivot
-#pragma unroll
-                        for (int s = 0; s < S; ++s) a[q][s] = cfnma(a[q][s], fm, rowbuf[h * S + s]);
-                        if (h == hj) a[q][sj] = cneg(fm);
-                        if (pos[q] == c) pos[q] = p;
+                    if (r < n && pos[q] >= k0) {
+                        const double v = cabs1(a[q][0]);
+                        const int key = make_key(pos[q], r);
+                        if (v > bv || (v == bv && key < bkey)) { bv = v; bkey = key; }
                     }
                 }
             }
+            wave_argmax(bv, bkey);
+            if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
         }
         __syncthreads();
+        // ---------------- kw Gauss-Jordan column steps on the register strips
+        // (compile-time recursion over the panel column: every strip index is a constant)
+        if (!(dbg & 1)) {
+            PanelCtx<NB, CPR, RPT> ctx{a, pos, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, ipiv,
+                                       n, k0, kw, tid, lane, wave, h, tr};
+            PanelSteps<NB, CPR, RPT, 0>::run(ctx);
+        }
         // ---------------- strips -> P (logical rows) and the row map
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
@@ -188,43 +285,70 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
             const int r = t / kw, j = t - r * kw;
             nxt[(size_t)r * n + k0 + j] = P[(size_t)r * PITCH + j];
         }
-        // ---------------- trailing update: one 16 x 16 tile per wave iteration
-        const int first_pt = k0 >> 4, last_pt = (k0 + kw - 1) >> 4;     // column tiles touching the panel
-        const bool panel_full_tiles = ((k0 & 15) == 0) && (((k0 + kw) & 15) == 0 || k0 + kw == n);
-        for (int item = wave; item < tiles * tiles; item += GJB_WAVES) {
-            const int tj = item / tiles, ti = item - tj * tiles;          // column-major: consecutive items share Q
-            if (panel_full_tiles && tj >= first_pt && tj <= last_pt) continue;
+        // ---------------- trailing update
+        // column tiles fully inside the panel are skipped; a tile that only touches it
+        // (NB = 8, or the ragged last panel) is computed and its panel columns masked
+        const int pt_lo = (k0 + 15) >> 4;                 // first tile fully inside [k0, k0+kw) ...
+        const int pt_hi = (k0 + kw) >> 4;                 // ... up to (excluding) this one
+        const int n_skip = max(0, pt_hi - pt_lo);
+        const int ct = tiles - n_skip;                    // column tiles to process
+        const int rhalf = (tiles + 1) >> 1;               // row tiles in the first half
+        for (int item = wave; item < ct * 2; item += GJB_WAVES) {
+            const int cx = item >> 1, part = item & 1;
+            const int tj = (n_skip > 0 && cx >= pt_lo) ? cx + n_skip : cx;
+            const int ti0 = part ? rhalf : 0, ti1 = part ? tiles : rhalf;
             const int col = tj * 16 + fi;
             const bool col_ok = col < n;
-            d4 accr = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
-            // C init: old[src[i]][col] unless i is a pivot-block row
-            int row_i[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                row_i[r] = i;
-                if (i < n && col_ok && !(i >= k0 && i < k0 + kw)) {
-                    const cplx v = cur[(size_t)src[i] * n + col];
-                    accr[r] = v.x; acci[r] = v.y;
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < NB; ks += 4) {
-                if (ks < kw) {
-                    const cplx pa = P[(size_t)(ti * 16 + fi) * PITCH + ks + fk];
-                    cplx qb = cmake(0.0, 0.0);
-                    const int k = ks + fk;
-                    if (k < kw && col_ok) qb = cur[(size_t)src[k0 + k] * n + col];
-                    accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qb.x, accr, 0, 0, 0);
-                    accr = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa.y, qb.y, accr, 0, 0, 0);
-                    acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qb.y, acci, 0, 0, 0);
-                    acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qb.x, acci, 0, 0, 0);
-                }
-            }
             const bool col_store = col_ok && !(col >= k0 && col < k0 + kw);
+            // Q fragments of this column tile: Q[k][col] = old[src[k0+k]][col]
+            cplx qf[KS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (row_i[r] < n && col_store) nxt[(size_t)row_i[r] * n + col] = cmake(accr[r], acci[r]);
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 4 + fk;
+                qf[ks] = cmake(0.0, 0.0);
+                if (k < kw && col_ok && !(dbg & 4)) qf[ks] = cur[(size_t)src[k0 + k] * n + col];
+            }
+            // C tiles are prefetched two row tiles ahead (three tiles of loads in flight per wave
+            // with the one being consumed): keeps enough bytes in flight to cover HBM latency
+            auto load_c = [&](int ti, cplx (&dst)[4]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + fk + 4 * r;
+                    dst[r] = cmake(0.0, 0.0);
+                    if (ti < ti1 && i < n && col_ok && !(i >= k0 && i < k0 + kw) && !(dbg & 4))
+                        dst[r] = cur[(size_t)src[i] * n + col];
+                }
+            };
+            cplx c0[4], c1[4];
+            load_c(ti0, c0);
+            load_c(ti0 + 1, c1);
+            for (int ti = ti0; ti < ti1; ++ti) {
+                d4 accr, acci;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { accr[r] = c0[r].x; acci[r] = c0[r].y; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c0[r] = c1[r];
+                load_c(ti + 2, c1);
+                const cplx* prow = P + (size_t)(ti * 16 + fi) * PITCH + fk;
+                cplx pa[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) pa[ks] = prow[ks * 4];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks * 4 < kw) {
+                        if (dbg & 2) { accr[0] += pa[ks].x * qf[ks].x; acci[0] += pa[ks].y * qf[ks].y; continue; }
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qf[ks].x, accr, 0, 0, 0);
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, -qf[ks].y, accr, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qf[ks].y, acci, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qf[ks].x, acci, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + fk + 4 * r;
+                    if (i < n && col_store) nxt[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                }
+            }
         }
         // swap buffers
         cplx* tmp = cur; cur = nxt; nxt = tmp;
@@ -241,10 +365,25 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
         info[blockIdx.x] = bad_sh;
     }
     __syncthreads();
-    for (int i = wave; i < n; i += GJB_WAVES) {
-        const cplx* srow = cur + (size_t)i * n;
-        cplx* drow = nxt + (size_t)i * n;
-        for (int j = lane; j < n; j += 64) drow[j] = srow[colsrc[j]];
+    // four rows per wave iteration: up to 16 independent gathers in flight per lane
+    for (int i0 = wave * 4; i0 < n; i0 += GJB_WAVES * 4) {
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            cplx v[4][4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int i = i0 + rr, j = j0 + jj * 64 + lane;
+                    v[rr][jj] = (i < n && j < n) ? cur[(size_t)i * n + colsrc[j]] : cmake(0.0, 0.0);
+                }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int i = i0 + rr, j = j0 + jj * 64 + lane;
+                    if (i < n && j < n) nxt[(size_t)i * n + j] = v[rr][jj];
+                }
+        }
     }
 }
 
@@ -257,12 +396,12 @@ size_t gj_smem(int n)
            3 * rows16 * sizeof(int);
 }
 
-constexpr size_t LDS_LIMIT = 160 * 1024 - 256;       // static __shared__ of the kernel is < 256 B
+constexpr size_t LDS_LIMIT = 160 * 1024 - 512;       // static __shared__ of the kernel is < 512 B
 
 template <int NB, int CPR, int RPT>
 bool gj_fits(int n)
 {
-    return n <= GjCfg<NB, CPR, RPT>::ROWS && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
+    return n <= GjCfg<NB, CPR, RPT>::ROWS && n < 4096 && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
 }
 
 template <int NB, int CPR, int RPT>
@@ -276,7 +415,9 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
                                   (int)LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("NEGF_GJ_DEBUG"); dbg = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg);
 }
 
 // which configuration serves dimension n: 0 = none
