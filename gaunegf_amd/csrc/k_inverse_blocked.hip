@@ -4,31 +4,36 @@
 // Replaces G = solve(E S - F - Sigma, I)  (gauNEGF/integrate.py:71, utils.py:52-54,
 // transport.py:154,163,186) for every energy point of the grid.
 //
-// Algorithm (block column K = columns [k0, k0+kw), kw <= NB):
-//   1. PANEL.  The n x kw panel is held in REGISTERS, one row strip per thread
-//      (S complex128 per strip).  kw unblocked Gauss-Jordan column steps with
-//      partial pivoting (LAPACK izamax rule |re|+|im|, first maximum) run on the
-//      strips; only the pivot row (NB values), the pivot column (n values) and the
-//      per-wave arg-max partials go through LDS (two barriers per column step; the
-//      pivot search of step j+1 is fused into the update of step j; the wave-level
-//      arg-max uses DPP lane moves, not LDS permutes).  Rows are never moved: each
-//      strip carries its logical position `pos`; the interchange sequence ipiv[] is
-//      recorded.  After the kw steps the panel equals the block column of the
-//      elementary transform  M_K = [ -A01 A11^-1 ; A11^-1 ; -A21 A11^-1 ].
-//   2. The strips are written to LDS as P (logical row order) together with the row
-//      map src[] (new logical row i <- old row src[i]).
-//   3. TRAILING UPDATE on the matrix cores, OUT OF PLACE (ping-pong buffers), which
-//      folds the row interchanges into the tile loads and removes every in-place
-//      hazard:     new[i][J] = (i in K ? 0 : old[src[i]][J]) + P[i][:] * Q[:][J],
-//      Q[k][J] = old[src[k0+k]][J];   new[:, K] = P.
-//      Work item = (column tile J, half of the row tiles): the wave loads the Q
-//      fragments of J once into registers and sweeps its row tiles, prefetching the
-//      next C tile while the current 16x16 tile runs its 4*NB/4 MFMAs
-//      (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
-//   4. After the last panel the column interchanges are undone (reverse order) while
-//      copying to the other buffer.
-// Flops: 8 n^3 per matrix (complex MAC = 8), the LU + triangular-inversion optimum;
-// every step updates the full n x n matrix, so the MFMA work per step is uniform.
+// The matrix is reduced IN PLACE and rows are NEVER moved ("implicit pivoting"):
+// instead of swapping the pivot row into position c, the kernel records
+//     pivrow[c] = physical row used as pivot for column c,   colof[r] = c.
+// Row operations alone reduce A to a permutation matrix, T A = Pi, and the in-place
+// trick stores column r_c of T in the storage of column c, so at the end
+//     G[i][j] = W[pivrow[i]][colof[j]]                       (one gather pass).
+// Keeping every row at its address makes each 16x16 tile update a pure
+// read-modify-write by one wave and keeps the working set of the in-flight batch at
+// one matrix per workgroup (256 x 640 KB = 164 MB at n = 200: resident in the 256 MB
+// Infinity Cache instead of streaming through HBM every panel step).
+//
+// Per block column K = [k0, k0+kw), kw <= NB:
+//   1. PANEL.  The n x kw panel lives in REGISTERS, one row strip per thread.  kw
+//      unblocked Gauss-Jordan column steps with partial pivoting (|re|+|im| as LAPACK
+//      izamax; among not-yet-used rows) run on the strips; only the pivot row, the
+//      pivot column and the per-wave arg-max partials go through LDS: two barriers
+//      per column step, the search for column j+1 is fused into the update of column
+//      j, the wave arg-max uses DPP lane moves, and waves that do not hold the pivot
+//      row run a select-free update.  Result: the block column of the elementary
+//      transform M_K, i.e.  P = [ -A0K AKK^-1 ; AKK^-1 ; -A2K AKK^-1 ]  (physical rows).
+//   2. P -> LDS (A operand of the update) and -> the panel columns of the matrix;
+//      the kw pivot rows Q = W[pivrow[k0..], :] are snapshotted to a scratch area.
+//   3. TRAILING UPDATE on the matrix cores, in place:
+//         W[i][J] = (i pivot row of this panel ? 0 : W[i][J]) + P[i][:] * Q[:][J]
+//      Work item = (column tile J, half of the row tiles): Q fragments of J in
+//      registers, row tiles swept with the next two C tiles prefetched; a 16x16
+//      complex tile = 4 real v_mfma_f64_16x16x4_f64 chains per 4-deep k-step.
+// Flops: 8 n^3 per matrix (complex MAC = 8) -- the LU + triangular-inversion optimum.
+// Ties in the pivot search are broken by the lower physical row index (LAPACK: lower
+// logical index); this only matters for exactly equal |.|_1 values.
 //
 // Data layout: row-major complex128 (interleaved), ld = n.  A lane fetches one
 // complex element (16 B) per MFMA operand; 16 lanes cover 256 contiguous bytes of
@@ -48,6 +53,7 @@ struct GjCfg {
     static constexpr int TPR = GJB_THREADS / CPR;  // threads along the row dimension
     static constexpr int ROWS = TPR * RPT;         // row capacity
     static constexpr int PITCH = NB + 1;           // LDS row pitch of P in complex (odd -> conflict free)
+    static constexpr int WPG = GJB_WAVES / CPR;    // waves per column part (owner group size)
 };
 
 struct RedSlot { double v; int key; int pad; };
@@ -89,15 +95,15 @@ __device__ __forceinline__ void wave_argmax(double& v, int& key)
 }
 
 constexpr int KEY_NONE = 0x7fffffff;
-__device__ __forceinline__ int make_key(int pos, int phys) { return (pos << 12) | phys; }
 
 // ---- one Gauss-Jordan column step on the register strips, J known at compile time ----
 template <int NB, int CPR, int RPT>
 struct PanelCtx {
     cplx (&a)[RPT][NB / CPR];
-    int (&pos)[RPT];
-    cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh; int* ipiv;
-    int n, k0, kw, tid, lane, wave, h, tr;
+    bool (&avail)[RPT];              // row not used as a pivot yet
+    cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh;
+    int* pivrow; int* colof;
+    int n, k0, kw, tid, lane, wave, h, tr, wave_tr0;
 };
 
 template <int NB, int CPR, int RPT, int J>
@@ -105,29 +111,45 @@ struct PanelSteps {
     static __device__ __forceinline__ void run(PanelCtx<NB, CPR, RPT>& x)
     {
         using C = GjCfg<NB, CPR, RPT>;
-        constexpr int S = C::S, TPR = C::TPR;
+        constexpr int S = C::S, TPR = C::TPR, WPG = C::WPG;
         constexpr int hj = J / S, sj = J % S;
         if (J < x.kw) {                                     // uniform branch
             const int c = x.k0 + J;
-            RedSlot* red = x.red + (J & 1) * GJB_WAVES;
-            // (1) combine the per-wave partials published by the previous step
-            double wv = red[0].v; int wkey = red[0].key;
+            // (1) combine the partials published by the waves that own column J
+            const RedSlot* red = x.red + (J & 1) * GJB_WAVES + hj * WPG;
+            double wv = red[0].v; int pphys = red[0].key;
 #pragma unroll
-            for (int w = 1; w < GJB_WAVES; ++w) {
+            for (int w = 1; w < WPG; ++w) {
                 const double ov = red[w].v; const int ok = red[w].key;
-                const bool take = (ov > wv) | ((ov == wv) & (ok < wkey));
-                wv = take ? ov : wv; wkey = take ? ok : wkey;
+                const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
+                wv = take ? ov : wv; pphys = take ? ok : pphys;
             }
-            int p, pphys;
-            if (wkey != KEY_NONE) { p = wkey >> 12; pphys = wkey & 0xFFF; }
-            else { p = c; pphys = -1; }                     // NaN column: keep the diagonal row
             if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // exactly singular / NaN
+            // a column of NaNs yields no candidate: fall back to any still-available row so the
+            // bookkeeping stays a permutation (the result is NaN anyway and info is set)
+            if (pphys == KEY_NONE) {
+                int cand = KEY_NONE;
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const int r = x.tr + q * TPR;
+                    if (x.h == 0 && r < x.n && x.avail[q]) cand = min(cand, r);
+                }
+                double dv = 0.0;
+                int k2 = cand;
+                // min over the workgroup via the same machinery (negated key trick not needed: use LDS)
+                __syncthreads();
+                if (x.tid == 0) x.red[0].pad = KEY_NONE;
+                __syncthreads();
+                if (k2 != KEY_NONE) atomicMin(&x.red[0].pad, k2);
+                __syncthreads();
+                pphys = x.red[0].pad;
+                (void)dv;
+            }
             // (2) publish the unscaled pivot row, 1/pivot and the pivot column
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
                 const int r = x.tr + q * TPR;
-                const bool is_piv = (pphys >= 0) ? (r == pphys) : (x.pos[q] == c && r < x.n);
-                if (is_piv) {
+                if (r == pphys) {
 #pragma unroll
                     for (int s = 0; s < S; ++s) x.rowbuf[x.h * S + s] = x.a[q][s];
                     if (x.h == hj) {
@@ -140,53 +162,63 @@ struct PanelSteps {
                 }
                 if (x.h == hj) x.colbuf[r] = x.a[q][sj];
             }
-            if (x.tid == 0) x.ipiv[c] = p;
+            if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
             __syncthreads();
-            // (3) rank-1 update of every strip.  One batch of LDS reads (pivot row part, 1/pivot,
-            //     own pivot-column entries), then pure register arithmetic.  The pivot row and
-            //     the other rows share one form  a <- base + coef * rowbuf:
-            //        pivot row : base = 0, coef = 1/pivot        (row / pivot)
-            //        other rows: base = a, coef = -(f / pivot)   (row - f/pivot * pivot row)
-            //     and the pivot-column entry becomes coef in both cases.
+            // (3) rank-1 update of every strip: one batch of LDS reads, then register arithmetic
             const cplx ip = *x.piv_ip;
             cplx rb[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) rb[s] = x.rowbuf[x.h * S + s];
-            cplx fcol[RPT];
+            cplx nfm[RPT];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) fcol[q] = x.colbuf[x.tr + q * TPR];
+            for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tr + q * TPR], ip));   // -(f / pivot)
+            bool wave_has_piv = false;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int r = x.tr + q * TPR;
-                const bool is_piv = (pphys >= 0) ? (r == pphys) : (x.pos[q] == c && r < x.n);
-                const cplx nfm = cneg(cmul(fcol[q], ip));
-                const cplx coef = is_piv ? ip : nfm;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s];
-                    x.a[q][s] = cfma(base, coef, rb[s]);
-                }
-                if (x.h == hj) x.a[q][sj] = coef;
-                x.pos[q] = is_piv ? c : (x.pos[q] == c ? p : x.pos[q]);
+                const int d = pphys - q * TPR - x.wave_tr0;
+                wave_has_piv |= (d >= 0 && d < 64);
             }
-            // (4) pivot search for column J+1 on the freshly updated strips
+            if (!wave_has_piv) {
+                // select-free path: row <- row - (f/pivot) * pivot row ; pivot-column entry <- -(f/pivot)
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) x.a[q][s] = cfma(x.a[q][s], nfm[q], rb[s]);
+                    if (x.h == hj) x.a[q][sj] = nfm[q];
+                }
+            } else {
+                // the wave holding the pivot row: that row becomes (pivot row) / pivot, entry 1/pivot
+#pragma unroll
+                for (int q = 0; q < RPT; ++q) {
+                    const bool is_piv = (x.tr + q * TPR) == pphys;
+                    const cplx coef = is_piv ? ip : nfm[q];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s];
+                        x.a[q][s] = cfma(base, coef, rb[s]);
+                    }
+                    if (x.h == hj) x.a[q][sj] = coef;
+                    x.avail[q] = x.avail[q] && !is_piv;
+                }
+            }
+            // (4) pivot search for column J+1 on the freshly updated strips (owner waves only)
             if constexpr (J + 1 < NB) {
                 constexpr int hn = (J + 1) / S, sn = (J + 1) % S;
-                double bv = -1.0; int bkey = KEY_NONE;
-                if (x.h == hn && J + 1 < x.kw) {
+                if (x.h == hn && J + 1 < x.kw) {            // wave-uniform: a wave belongs to one column part
+                    double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
                     for (int q = 0; q < RPT; ++q) {
                         const int r = x.tr + q * TPR;
-                        if (r < x.n && x.pos[q] >= c + 1) {
+                        if (r < x.n && x.avail[q]) {
                             const double v = cabs1(x.a[q][sn]);
-                            const int key = make_key(x.pos[q], r);
-                            if (v > bv || (v == bv && key < bkey)) { bv = v; bkey = key; }
+                            const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                            bv = take ? v : bv; bkey = take ? r : bkey;
                         }
                     }
+                    wave_argmax(bv, bkey);
+                    RedSlot* rn = x.red + ((J + 1) & 1) * GJB_WAVES;
+                    if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
                 }
-                wave_argmax(bv, bkey);
-                RedSlot* rn = x.red + ((J + 1) & 1) * GJB_WAVES;
-                if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
             }
             __syncthreads();
             if constexpr (J + 1 < NB) PanelSteps<NB, CPR, RPT, J + 1>::run(x);
@@ -205,23 +237,24 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int rows16 = (n + 15) & ~15;
-    cplx* P = reinterpret_cast<cplx*>(smem_raw);                 // [rows16][PITCH]
-    cplx* rowbuf = P + (size_t)rows16 * PITCH;                   // [NB]  unscaled pivot row
+    cplx* P = reinterpret_cast<cplx*>(smem_raw);                 // [rows16][PITCH]  physical rows
+    cplx* rowbuf = P + (size_t)rows16 * PITCH;                   // [NB]   unscaled pivot row
     cplx* colbuf = rowbuf + NB;                                  // [ROWS] pivot column
-    int* src = reinterpret_cast<int*>(colbuf + C::ROWS);         // [rows16] new row i <- old row src[i]
-    int* ipiv = src + rows16;                                    // [n]
-    int* colsrc = ipiv + rows16;                                 // [rows16]
+    int* pivrow = reinterpret_cast<int*>(colbuf + C::ROWS);      // [rows16] physical pivot row of column c
+    int* colof = pivrow + rows16;                                // [rows16] column a row was pivot for, or -1
     __shared__ RedSlot red[2][GJB_WAVES];
     __shared__ cplx piv_ip;
     __shared__ int bad_sh;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = tid / TPR;                 // which column part of the panel this thread holds
+    const int h = tid / TPR;                 // column part of the panel held by this thread (wave-uniform)
     const int tr = tid - h * TPR;            // row slot
-    cplx* cur = bufA + (size_t)blockIdx.x * mat_stride;
-    cplx* nxt = bufB + (size_t)blockIdx.x * mat_stride;
+    const int wave_tr0 = (tid & ~63) - h * TPR;
+    cplx* W = bufA + (size_t)blockIdx.x * mat_stride;            // the matrix, updated in place
+    cplx* X = bufB + (size_t)blockIdx.x * mat_stride;            // Q snapshots, then the result
 
     if (tid == 0) bad_sh = 0;
+    for (int t = tid; t < rows16; t += GJB_THREADS) { colof[t] = -1; pivrow[t] = 0; }
     // rows >= n of P stay zero for the whole kernel (A operand of the edge tiles)
     for (int t = tid; t < (rows16 - n) * PITCH; t += GJB_THREADS) P[(size_t)n * PITCH + t] = cmake(0.0, 0.0);
 
@@ -230,32 +263,30 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int kw = min(NB, n - k0);
-        __syncthreads();
+        __syncthreads();                 // previous trailing update (stores to W, reads of P/colof) is complete
         // ---------------- panel: global -> register strips.  Every thread fetches its own strip
         // (S independent 16-byte loads issued back to back: one memory latency per panel)
         cplx a[RPT][S];
-        int pos[RPT];
+        bool avail[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int r = tr + q * TPR;
-            pos[q] = r;
-            const cplx* g = cur + (size_t)(r < n ? r : 0) * n + k0 + h * S;
+            avail[q] = (r < n) && (colof[r < rows16 ? r : 0] < 0);
+            const cplx* g = W + (size_t)(r < n ? r : 0) * n + k0 + h * S;
 #pragma unroll
             for (int s = 0; s < S; ++s)
                 a[q][s] = (r < n && h * S + s < kw) ? g[s] : cmake(0.0, 0.0);
         }
-        // ---------------- pivot search for the first column of the panel
-        if (!(dbg & 1)) {
+        // ---------------- pivot search for the first column of the panel (waves holding column part 0)
+        if (!(dbg & 1) && h == 0) {
             double bv = -1.0; int bkey = KEY_NONE;
-            if (h == 0) {
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int r = tr + q * TPR;
-                    if (r < n && pos[q] >= k0) {
-                        const double v = cabs1(a[q][0]);
-                        const int key = make_key(pos[q], r);
-                        if (v > bv || (v == bv && key < bkey)) { bv = v; bkey = key; }
-                    }
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tr + q * TPR;
+                if (r < n && avail[q]) {
+                    const double v = cabs1(a[q][0]);
+                    const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                    bv = take ? v : bv; bkey = take ? r : bkey;
                 }
             }
             wave_argmax(bv, bkey);
@@ -265,27 +296,34 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
         // ---------------- kw Gauss-Jordan column steps on the register strips
         // (compile-time recursion over the panel column: every strip index is a constant)
         if (!(dbg & 1)) {
-            PanelCtx<NB, CPR, RPT> ctx{a, pos, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, ipiv,
-                                       n, k0, kw, tid, lane, wave, h, tr};
+            PanelCtx<NB, CPR, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
+                                       n, k0, kw, tid, lane, wave, h, tr, wave_tr0};
             PanelSteps<NB, CPR, RPT, 0>::run(ctx);
+        } else if (tid == 0) {
+            for (int j = 0; j < kw; ++j) { pivrow[k0 + j] = k0 + j; colof[k0 + j] = k0 + j; }
         }
-        // ---------------- strips -> P (logical rows) and the row map
+        // ---------------- strips -> P (physical rows: no scatter)
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int r = tr + q * TPR;
             if (r < n) {
 #pragma unroll
-                for (int s = 0; s < S; ++s) P[(size_t)pos[q] * PITCH + h * S + s] = a[q][s];
-                if (h == 0) src[pos[q]] = r;
+                for (int s = 0; s < S; ++s) P[(size_t)r * PITCH + h * S + s] = a[q][s];
             }
         }
         __syncthreads();
-        // ---------------- panel columns of the new buffer
+        // ---------------- panel columns of the matrix <- P ; pivot rows -> Q snapshot X[k][:]
         for (int t = tid; t < n * kw; t += GJB_THREADS) {
             const int r = t / kw, j = t - r * kw;
-            nxt[(size_t)r * n + k0 + j] = P[(size_t)r * PITCH + j];
+            W[(size_t)r * n + k0 + j] = P[(size_t)r * PITCH + j];
         }
-        // ---------------- trailing update
+        for (int k = wave; k < kw; k += GJB_WAVES) {
+            const cplx* srow = W + (size_t)pivrow[k0 + k] * n;
+            cplx* drow = X + (size_t)k * n;
+            for (int j = lane; j < n; j += 64) drow[j] = srow[j];
+        }
+        __syncthreads();                 // Q snapshot visible; nobody reads a pivot row of W after this point
+        // ---------------- trailing update (in place)
         // column tiles fully inside the panel are skipped; a tile that only touches it
         // (NB = 8, or the ragged last panel) is computed and its panel columns masked
         const int pt_lo = (k0 + 15) >> 4;                 // first tile fully inside [k0, k0+kw) ...
@@ -300,23 +338,24 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
             const int col = tj * 16 + fi;
             const bool col_ok = col < n;
             const bool col_store = col_ok && !(col >= k0 && col < k0 + kw);
-            // Q fragments of this column tile: Q[k][col] = old[src[k0+k]][col]
+            // Q fragments of this column tile: Q[k][col]
             cplx qf[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int k = ks * 4 + fk;
                 qf[ks] = cmake(0.0, 0.0);
-                if (k < kw && col_ok && !(dbg & 4)) qf[ks] = cur[(size_t)src[k0 + k] * n + col];
+                if (k < kw && col_ok && !(dbg & 4)) qf[ks] = X[(size_t)k * n + col];
             }
-            // C tiles are prefetched two row tiles ahead (three tiles of loads in flight per wave
-            // with the one being consumed): keeps enough bytes in flight to cover HBM latency
+            // C tiles are prefetched two row tiles ahead; rows used as pivots in this panel start from 0
             auto load_c = [&](int ti, cplx (&dst)[4]) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = ti * 16 + fk + 4 * r;
                     dst[r] = cmake(0.0, 0.0);
-                    if (ti < ti1 && i < n && col_ok && !(i >= k0 && i < k0 + kw) && !(dbg & 4))
-                        dst[r] = cur[(size_t)src[i] * n + col];
+                    if (ti < ti1 && i < n && col_ok && !(dbg & 4)) {
+                        const int cf = colof[i];
+                        if (!(cf >= k0 && cf < k0 + kw)) dst[r] = W[(size_t)i * n + col];
+                    }
                 }
             };
             cplx c0[4], c1[4];
@@ -346,26 +385,15 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = ti * 16 + fk + 4 * r;
-                    if (i < n && col_store) nxt[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                    if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
                 }
             }
         }
-        // swap buffers
-        cplx* tmp = cur; cur = nxt; nxt = tmp;
     }
     __syncthreads();
-    // ---------------- undo the column interchanges (reverse order) while copying
-    for (int t = tid; t < n; t += GJB_THREADS) colsrc[t] = t;
-    __syncthreads();
-    if (tid == 0) {
-        for (int c = n - 1; c >= 0; --c) {
-            const int p = ipiv[c];
-            if (p != c) { const int x = colsrc[c]; colsrc[c] = colsrc[p]; colsrc[p] = x; }
-        }
-        info[blockIdx.x] = bad_sh;
-    }
-    __syncthreads();
-    // four rows per wave iteration: up to 16 independent gathers in flight per lane
+    if (tid == 0) info[blockIdx.x] = bad_sh;
+    // ---------------- G[i][j] = W[pivrow[i]][colof[j]] : four rows per wave iteration,
+    // up to 16 independent gathers in flight per lane
     for (int i0 = wave * 4; i0 < n; i0 += GJB_WAVES * 4) {
         for (int j0 = 0; j0 < n; j0 += 256) {
             cplx v[4][4];
@@ -374,14 +402,14 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int i = i0 + rr, j = j0 + jj * 64 + lane;
-                    v[rr][jj] = (i < n && j < n) ? cur[(size_t)i * n + colsrc[j]] : cmake(0.0, 0.0);
+                    v[rr][jj] = (i < n && j < n) ? W[(size_t)pivrow[i] * n + colof[j]] : cmake(0.0, 0.0);
                 }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int i = i0 + rr, j = j0 + jj * 64 + lane;
-                    if (i < n && j < n) nxt[(size_t)i * n + j] = v[rr][jj];
+                    if (i < n && j < n) X[(size_t)i * n + j] = v[rr][jj];
                 }
         }
     }
@@ -393,7 +421,7 @@ size_t gj_smem(int n)
     using C = GjCfg<NB, CPR, RPT>;
     const size_t rows16 = (size_t)((n + 15) & ~15);
     return rows16 * C::PITCH * sizeof(cplx) + NB * sizeof(cplx) + (size_t)C::ROWS * sizeof(cplx) +
-           3 * rows16 * sizeof(int);
+           2 * rows16 * sizeof(int);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024 - 512;       // static __shared__ of the kernel is < 512 B
@@ -401,7 +429,7 @@ constexpr size_t LDS_LIMIT = 160 * 1024 - 512;       // static __shared__ of the
 template <int NB, int CPR, int RPT>
 bool gj_fits(int n)
 {
-    return n <= GjCfg<NB, CPR, RPT>::ROWS && n < 4096 && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
+    return n <= GjCfg<NB, CPR, RPT>::ROWS && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
 }
 
 template <int NB, int CPR, int RPT>
@@ -420,36 +448,29 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
     hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg);
 }
 
-// which configuration serves dimension n: 0 = none
+// which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
 int gj_pick(int n)
 {
-    if (n < 16) return 0;                               // tiny matrices: the unblocked kernel
+    if (n < 32) return 0;                               // small matrices: the unblocked kernel
     if (gj_fits<32, 2, 1>(n)) return 1;                 // n <= 256, panel 32
     if (gj_fits<16, 1, 1>(n)) return 2;                 // n <= 512, panel 16
     if (gj_fits<8, 1, 2>(n)) return 3;                  // n <= ~960, panel 8
     return 0;
 }
 
-int gj_panels(int n, int cfg)
-{
-    const int NB = cfg == 1 ? 32 : (cfg == 2 ? 16 : 8);
-    return (n + NB - 1) / NB;
-}
-
 }  // namespace
 
 bool inverse_blocked_supported(int n) { return gj_pick(n) != 0; }
 
-// Returns true when the result ends up in B (the ping-pong parity), false when in A.
+// In-place reduction of A with B as scratch; the inverses are gathered into B.
+// Returns true: the result is in B.
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
-    const int cfg = gj_pick(n);
-    switch (cfg) {
+    switch (gj_pick(n)) {
     case 1: gj_launch<32, 2, 1>(st, n, nb, A, B, stride, info); break;
     case 2: gj_launch<16, 1, 1>(st, n, nb, A, B, stride, info); break;
     case 3: gj_launch<8, 1, 2>(st, n, nb, A, B, stride, info); break;
     default: return false;
     }
-    // np panel passes + 1 unscramble pass, each flipping the buffer
-    return ((gj_panels(n, cfg) + 1) & 1) != 0;
+    return true;
 }
