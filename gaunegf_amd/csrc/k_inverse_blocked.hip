@@ -24,13 +24,17 @@
 //      j, the wave arg-max uses DPP lane moves, and waves that do not hold the pivot
 //      row run a select-free update.  Result: the block column of the elementary
 //      transform M_K, i.e.  P = [ -A0K AKK^-1 ; AKK^-1 ; -A2K AKK^-1 ]  (physical rows).
-//   2. P -> LDS (A operand of the update) and -> the panel columns of the matrix;
-//      the kw pivot rows Q = W[pivrow[k0..], :] are snapshotted to a scratch area.
+//   2. The strips are stored straight into the panel columns of the matrix (P is not
+//      kept in LDS: the kernel needs < 8 KB of LDS and <= 128 VGPRs, so TWO workgroups
+//      share a CU and one matrix's latency-bound panel phase overlaps the other's
+//      MFMA/memory-bound update); the kw pivot rows Q = W[pivrow[k0..], :] are
+//      snapshotted to a scratch area.
 //   3. TRAILING UPDATE on the matrix cores, in place:
 //         W[i][J] = (i pivot row of this panel ? 0 : W[i][J]) + P[i][:] * Q[:][J]
-//      Work item = (column tile J, half of the row tiles): Q fragments of J in
-//      registers, row tiles swept with the next two C tiles prefetched; a 16x16
-//      complex tile = 4 real v_mfma_f64_16x16x4_f64 chains per 4-deep k-step.
+//      Work item = (row tile I, chunk of 4 column tiles): the P fragments of I are
+//      fetched once (L2-hot: just written by this CU), then per column tile the Q
+//      fragments and the C tile; a 16x16 complex tile = 4 real v_mfma_f64_16x16x4_f64
+//      chains per 4-deep k-step (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
 // Flops: 8 n^3 per matrix (complex MAC = 8) -- the LU + triangular-inversion optimum.
 // Ties in the pivot search are broken by the lower physical row index (LAPACK: lower
 // logical index); this only matters for exactly equal |.|_1 values.
@@ -44,16 +48,18 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int GJB_THREADS = 512;
-constexpr int GJB_WAVES = GJB_THREADS / 64;
+constexpr int MAX_WAVES = 16;
 
-template <int NB, int CPR, int RPT>
+template <int T, int NB, int CPR, int RPT>
 struct GjCfg {
+    static constexpr int THREADS = T;
+    static constexpr int WAVES = T / 64;
     static constexpr int S = NB / CPR;             // complex values per strip
-    static constexpr int TPR = GJB_THREADS / CPR;  // threads along the row dimension
+    static constexpr int TPR = T / CPR;            // threads along the row dimension
     static constexpr int ROWS = TPR * RPT;         // row capacity
+    static constexpr int WPG = WAVES / CPR;        // waves per column part (owner group size)
     static constexpr int PITCH = NB + 1;           // LDS row pitch of P in complex (odd -> conflict free)
-    static constexpr int WPG = GJB_WAVES / CPR;    // waves per column part (owner group size)
+    static constexpr int RS = (WAVES >= 16) ? 4 : 2;   // row splits of a column tile in the update
 };
 
 struct RedSlot { double v; int key; int pad; };
@@ -97,7 +103,7 @@ __device__ __forceinline__ void wave_argmax(double& v, int& key)
 constexpr int KEY_NONE = 0x7fffffff;
 
 // ---- one Gauss-Jordan column step on the register strips, J known at compile time ----
-template <int NB, int CPR, int RPT>
+template <int T, int NB, int CPR, int RPT>
 struct PanelCtx {
     cplx (&a)[RPT][NB / CPR];
     bool (&avail)[RPT];              // row not used as a pivot yet
@@ -106,17 +112,17 @@ struct PanelCtx {
     int n, k0, kw, tid, lane, wave, h, tr, wave_tr0;
 };
 
-template <int NB, int CPR, int RPT, int J>
+template <int T, int NB, int CPR, int RPT, int J>
 struct PanelSteps {
-    static __device__ __forceinline__ void run(PanelCtx<NB, CPR, RPT>& x)
+    static __device__ __forceinline__ void run(PanelCtx<T, NB, CPR, RPT>& x)
     {
-        using C = GjCfg<NB, CPR, RPT>;
+        using C = GjCfg<T, NB, CPR, RPT>;
         constexpr int S = C::S, TPR = C::TPR, WPG = C::WPG;
         constexpr int hj = J / S, sj = J % S;
         if (J < x.kw) {                                     // uniform branch
             const int c = x.k0 + J;
             // (1) combine the partials published by the waves that own column J
-            const RedSlot* red = x.red + (J & 1) * GJB_WAVES + hj * WPG;
+            const RedSlot* red = x.red + (J & 1) * MAX_WAVES + hj * WPG;
             double wv = red[0].v; int pphys = red[0].key;
 #pragma unroll
             for (int w = 1; w < WPG; ++w) {
@@ -164,11 +170,9 @@ struct PanelSteps {
             }
             if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
             __syncthreads();
-            // (3) rank-1 update of every strip: one batch of LDS reads, then register arithmetic
+            // (3) rank-1 update of every strip in two half-strips (bounded register use): a batch of
+            //     LDS reads of the pivot row part, then register arithmetic
             const cplx ip = *x.piv_ip;
-            cplx rb[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) rb[s] = x.rowbuf[x.h * S + s];
             cplx nfm[RPT];
 #pragma unroll
             for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tr + q * TPR], ip));   // -(f / pivot)
@@ -178,28 +182,38 @@ struct PanelSteps {
                 const int d = pphys - q * TPR - x.wave_tr0;
                 wave_has_piv |= (d >= 0 && d < 64);
             }
-            if (!wave_has_piv) {
-                // select-free path: row <- row - (f/pivot) * pivot row ; pivot-column entry <- -(f/pivot)
+            constexpr int HS = (S >= 8) ? S / 2 : S;        // half-strip length
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
+            for (int s0 = 0; s0 < S; s0 += HS) {
+                cplx rb[HS];
 #pragma unroll
-                    for (int s = 0; s < S; ++s) x.a[q][s] = cfma(x.a[q][s], nfm[q], rb[s]);
-                    if (x.h == hj) x.a[q][sj] = nfm[q];
-                }
-            } else {
-                // the wave holding the pivot row: that row becomes (pivot row) / pivot, entry 1/pivot
+                for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[x.h * S + s0 + s];
+                if (!wave_has_piv) {
+                    // select-free path: row <- row - (f/pivot) * pivot row
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const bool is_piv = (x.tr + q * TPR) == pphys;
-                    const cplx coef = is_piv ? ip : nfm[q];
+                    for (int q = 0; q < RPT; ++q)
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s];
-                        x.a[q][s] = cfma(base, coef, rb[s]);
+                        for (int s = 0; s < HS; ++s) x.a[q][s0 + s] = cfma(x.a[q][s0 + s], nfm[q], rb[s]);
+                } else {
+                    // the wave holding the pivot row: that row becomes (pivot row) / pivot
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const bool is_piv = (x.tr + q * TPR) == pphys;
+                        const cplx coef = is_piv ? ip : nfm[q];
+#pragma unroll
+                        for (int s = 0; s < HS; ++s) {
+                            const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s0 + s];
+                            x.a[q][s0 + s] = cfma(base, coef, rb[s]);
+                        }
                     }
-                    if (x.h == hj) x.a[q][sj] = coef;
-                    x.avail[q] = x.avail[q] && !is_piv;
                 }
+            }
+            // pivot-column entry: 1/pivot on the pivot row, -(f/pivot) elsewhere
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const bool is_piv = (x.tr + q * TPR) == pphys;
+                if (x.h == hj) x.a[q][sj] = is_piv ? ip : nfm[q];
+                x.avail[q] = x.avail[q] && !is_piv;
             }
             // (4) pivot search for column J+1 on the freshly updated strips (owner waves only)
             if constexpr (J + 1 < NB) {
@@ -216,23 +230,24 @@ struct PanelSteps {
                         }
                     }
                     wave_argmax(bv, bkey);
-                    RedSlot* rn = x.red + ((J + 1) & 1) * GJB_WAVES;
+                    RedSlot* rn = x.red + ((J + 1) & 1) * MAX_WAVES;
                     if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
                 }
             }
             __syncthreads();
-            if constexpr (J + 1 < NB) PanelSteps<NB, CPR, RPT, J + 1>::run(x);
+            if constexpr (J + 1 < NB) PanelSteps<T, NB, CPR, RPT, J + 1>::run(x);
         }
     }
 };
 
-template <int NB, int CPR, int RPT>
-__global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
+template <int T, int NB, int CPR, int RPT>
+__global__ __launch_bounds__(T) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
     int dbg /* ablation switches, 0 in production: 1 = no pivot steps, 2 = no MFMA, 4 = no tile loads */)
 {
-    using C = GjCfg<NB, CPR, RPT>;
-    constexpr int S = C::S, TPR = C::TPR, PITCH = C::PITCH;
+    using C = GjCfg<T, NB, CPR, RPT>;
+    constexpr int S = C::S, TPR = C::TPR, PITCH = C::PITCH, RS = C::RS;
+    constexpr int GJB_THREADS = T, GJB_WAVES = C::WAVES;
     constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     cplx* colbuf = rowbuf + NB;                                  // [ROWS] pivot column
     int* pivrow = reinterpret_cast<int*>(colbuf + C::ROWS);      // [rows16] physical pivot row of column c
     int* colof = pivrow + rows16;                                // [rows16] column a row was pivot for, or -1
-    __shared__ RedSlot red[2][GJB_WAVES];
+    __shared__ RedSlot red[2][MAX_WAVES];
     __shared__ cplx piv_ip;
     __shared__ int bad_sh;
 
@@ -255,6 +270,7 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 
     if (tid == 0) bad_sh = 0;
     for (int t = tid; t < rows16; t += GJB_THREADS) { colof[t] = -1; pivrow[t] = 0; }
+
     // rows >= n of P stay zero for the whole kernel (A operand of the edge tiles)
     for (int t = tid; t < (rows16 - n) * PITCH; t += GJB_THREADS) P[(size_t)n * PITCH + t] = cmake(0.0, 0.0);
 
@@ -296,26 +312,27 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
         // ---------------- kw Gauss-Jordan column steps on the register strips
         // (compile-time recursion over the panel column: every strip index is a constant)
         if (!(dbg & 1)) {
-            PanelCtx<NB, CPR, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
+            PanelCtx<T, NB, CPR, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
                                        n, k0, kw, tid, lane, wave, h, tr, wave_tr0};
-            PanelSteps<NB, CPR, RPT, 0>::run(ctx);
+            PanelSteps<T, NB, CPR, RPT, 0>::run(ctx);
         } else if (tid == 0) {
             for (int j = 0; j < kw; ++j) { pivrow[k0 + j] = k0 + j; colof[k0 + j] = k0 + j; }
         }
-        // ---------------- strips -> P (physical rows: no scatter)
+        // ---------------- strips -> panel columns of the matrix (P, physical rows) ; pivot rows ->
+        // Q snapshot X[k][:].  pivrow[] of this panel was written before the last barrier of the
+        // pivot steps, so it is visible here.
+        if (dbg & 1) __syncthreads();
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int r = tr + q * TPR;
             if (r < n) {
+                cplx* g = W + (size_t)r * n + k0 + h * S;
 #pragma unroll
-                for (int s = 0; s < S; ++s) P[(size_t)r * PITCH + h * S + s] = a[q][s];
+                for (int s = 0; s < S; ++s) {
+                    if (h * S + s < kw) g[s] = a[q][s];
+                    P[(size_t)r * PITCH + h * S + s] = a[q][s];
+                }
             }
-        }
-        __syncthreads();
-        // ---------------- panel columns of the matrix <- P ; pivot rows -> Q snapshot X[k][:]
-        for (int t = tid; t < n * kw; t += GJB_THREADS) {
-            const int r = t / kw, j = t - r * kw;
-            W[(size_t)r * n + k0 + j] = P[(size_t)r * PITCH + j];
         }
         for (int k = wave; k < kw; k += GJB_WAVES) {
             const cplx* srow = W + (size_t)pivrow[k0 + k] * n;
@@ -330,15 +347,15 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
         const int pt_hi = (k0 + kw) >> 4;                 // ... up to (excluding) this one
         const int n_skip = max(0, pt_hi - pt_lo);
         const int ct = tiles - n_skip;                    // column tiles to process
-        const int rhalf = (tiles + 1) >> 1;               // row tiles in the first half
-        for (int item = wave; item < ct * 2; item += GJB_WAVES) {
-            const int cx = item >> 1, part = item & 1;
+        // work item = (column tile, one of RS row ranges): Q fragments in registers, P from LDS
+        const int rpart = (tiles + RS - 1) / RS;
+        for (int item = wave; item < ct * RS; item += GJB_WAVES) {
+            const int cx = item / RS, part = item - cx * RS;
             const int tj = (n_skip > 0 && cx >= pt_lo) ? cx + n_skip : cx;
-            const int ti0 = part ? rhalf : 0, ti1 = part ? tiles : rhalf;
+            const int ti0 = part * rpart, ti1 = min(tiles, ti0 + rpart);
             const int col = tj * 16 + fi;
             const bool col_ok = col < n;
             const bool col_store = col_ok && !(col >= k0 && col < k0 + kw);
-            // Q fragments of this column tile: Q[k][col]
             cplx qf[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -346,7 +363,8 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                 qf[ks] = cmake(0.0, 0.0);
                 if (k < kw && col_ok && !(dbg & 4)) qf[ks] = X[(size_t)k * n + col];
             }
-            // C tiles are prefetched two row tiles ahead; rows used as pivots in this panel start from 0
+            // the next C tile is prefetched while the current one runs its MFMAs; rows used as
+            // pivots in this panel start from zero
             auto load_c = [&](int ti, cplx (&dst)[4]) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -358,28 +376,23 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                     }
                 }
             };
-            cplx c0[4], c1[4];
+            cplx c0[4];
             load_c(ti0, c0);
-            load_c(ti0 + 1, c1);
             for (int ti = ti0; ti < ti1; ++ti) {
                 d4 accr, acci;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { accr[r] = c0[r].x; acci[r] = c0[r].y; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c0[r] = c1[r];
-                load_c(ti + 2, c1);
+                load_c(ti + 1, c0);
                 const cplx* prow = P + (size_t)(ti * 16 + fi) * PITCH + fk;
-                cplx pa[KS];
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) pa[ks] = prow[ks * 4];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (ks * 4 < kw) {
-                        if (dbg & 2) { accr[0] += pa[ks].x * qf[ks].x; acci[0] += pa[ks].y * qf[ks].y; continue; }
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qf[ks].x, accr, 0, 0, 0);
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, -qf[ks].y, accr, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qf[ks].y, acci, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qf[ks].x, acci, 0, 0, 0);
+                        const cplx pa = prow[ks * 4];
+                        if (dbg & 2) { accr[0] += pa.x * qf[ks].x; acci[0] += pa.y * qf[ks].y; continue; }
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].y, acci, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].x, acci, 0, 0, 0);
                     }
                 }
 #pragma unroll
@@ -415,28 +428,28 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     }
 }
 
-template <int NB, int CPR, int RPT>
+template <int T, int NB, int CPR, int RPT>
 size_t gj_smem(int n)
 {
-    using C = GjCfg<NB, CPR, RPT>;
+    using C = GjCfg<T, NB, CPR, RPT>;
     const size_t rows16 = (size_t)((n + 15) & ~15);
     return rows16 * C::PITCH * sizeof(cplx) + NB * sizeof(cplx) + (size_t)C::ROWS * sizeof(cplx) +
            2 * rows16 * sizeof(int);
 }
 
-constexpr size_t LDS_LIMIT = 160 * 1024 - 512;       // static __shared__ of the kernel is < 512 B
+constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;      // static __shared__ of the kernel is < 1 KB
 
-template <int NB, int CPR, int RPT>
+template <int T, int NB, int CPR, int RPT>
 bool gj_fits(int n)
 {
-    return n <= GjCfg<NB, CPR, RPT>::ROWS && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
+    return n <= GjCfg<T, NB, CPR, RPT>::ROWS && gj_smem<T, NB, CPR, RPT>(n) <= LDS_LIMIT;
 }
 
-template <int NB, int CPR, int RPT>
+template <int T, int NB, int CPR, int RPT>
 void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
-    auto kern = gj_blocked_kernel<NB, CPR, RPT>;
-    const size_t smem = gj_smem<NB, CPR, RPT>(n);
+    auto kern = gj_blocked_kernel<T, NB, CPR, RPT>;
+    const size_t smem = gj_smem<T, NB, CPR, RPT>(n);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -445,16 +458,24 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
     }
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("NEGF_GJ_DEBUG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(T), smem, st, n, A, B, stride, info, dbg);
+}
+
+int gj_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("NEGF_GJ_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 // which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
 int gj_pick(int n)
 {
     if (n < 32) return 0;                               // small matrices: the unblocked kernel
-    if (gj_fits<32, 2, 1>(n)) return 1;                 // n <= 256, panel 32
-    if (gj_fits<16, 1, 1>(n)) return 2;                 // n <= 512, panel 16
-    if (gj_fits<8, 1, 2>(n)) return 3;                  // n <= ~960, panel 8
+    if (gj_variant() == 1 && gj_fits<512, 32, 2, 1>(n)) return 4;      // 8-wave variant (A/B testing)
+    if (gj_fits<1024, 32, 4, 1>(n)) return 1;           // n <= 256, panel 32, 16 waves
+    if (gj_fits<1024, 16, 2, 1>(n)) return 2;           // n <= 512, panel 16
+    if (gj_fits<1024, 8, 1, 1>(n)) return 3;            // n <= ~900, panel 8
     return 0;
 }
 
@@ -467,9 +488,10 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0; }
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
     switch (gj_pick(n)) {
-    case 1: gj_launch<32, 2, 1>(st, n, nb, A, B, stride, info); break;
-    case 2: gj_launch<16, 1, 1>(st, n, nb, A, B, stride, info); break;
-    case 3: gj_launch<8, 1, 2>(st, n, nb, A, B, stride, info); break;
+    case 1: gj_launch<1024, 32, 4, 1>(st, n, nb, A, B, stride, info); break;
+    case 2: gj_launch<1024, 16, 2, 1>(st, n, nb, A, B, stride, info); break;
+    case 3: gj_launch<1024, 8, 1, 1>(st, n, nb, A, B, stride, info); break;
+    case 4: gj_launch<512, 32, 2, 1>(st, n, nb, A, B, stride, info); break;
     default: return false;
     }
     return true;
