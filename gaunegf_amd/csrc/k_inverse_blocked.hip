@@ -11,30 +11,28 @@
 // trick stores column r_c of T in the storage of column c, so at the end
 //     G[i][j] = W[pivrow[i]][colof[j]]                       (one gather pass).
 // Keeping every row at its address makes each 16x16 tile update a pure
-// read-modify-write by one wave and keeps the working set of the in-flight batch at
-// one matrix per workgroup (256 x 640 KB = 164 MB at n = 200: resident in the 256 MB
-// Infinity Cache instead of streaming through HBM every panel step).
+// read-modify-write by one wave.
 //
 // Per block column K = [k0, k0+kw), kw <= NB:
-//   1. PANEL.  The n x kw panel lives in REGISTERS, one row strip per thread.  kw
-//      unblocked Gauss-Jordan column steps with partial pivoting (|re|+|im| as LAPACK
-//      izamax; among not-yet-used rows) run on the strips; only the pivot row, the
-//      pivot column and the per-wave arg-max partials go through LDS: two barriers
-//      per column step, the search for column j+1 is fused into the update of column
-//      j, the wave arg-max uses DPP lane moves, and waves that do not hold the pivot
-//      row run a select-free update.  Result: the block column of the elementary
-//      transform M_K, i.e.  P = [ -A0K AKK^-1 ; AKK^-1 ; -A2K AKK^-1 ]  (physical rows).
-//   2. The strips are stored straight into the panel columns of the matrix (P is not
-//      kept in LDS: the kernel needs < 8 KB of LDS and <= 128 VGPRs, so TWO workgroups
-//      share a CU and one matrix's latency-bound panel phase overlaps the other's
-//      MFMA/memory-bound update); the kw pivot rows Q = W[pivrow[k0..], :] are
-//      snapshotted to a scratch area.
-//   3. TRAILING UPDATE on the matrix cores, in place:
+//   1. PANEL (waves 0..PW-1).  The n x kw panel lives in REGISTERS, one full row strip
+//      (NB complex128) per thread.  kw unblocked Gauss-Jordan column steps with partial
+//      pivoting (|re|+|im| as LAPACK izamax; among not-yet-used rows) run on the strips;
+//      only the pivot row, the pivot column and the per-wave arg-max partials go through
+//      LDS: two barriers per column step, the search for column j+1 is fused into the
+//      update of column j, the wave arg-max uses DPP lane moves, and waves that do not
+//      hold the pivot row run a select-free update.  The phase is VALU-issue bound
+//      (PMC: ~170 vector instructions per wave per step), so it runs on the FEWEST waves
+//      that can hold the panel: the per-wave bookkeeping is not replicated 8 or 16 times.
+//      Result: the block column of the elementary transform M_K, i.e.
+//      P = [ -A0K AKK^-1 ; AKK^-1 ; -A2K AKK^-1 ]  (physical rows).
+//   2. P -> LDS, k-major (conflict-free A-operand reads), and -> the panel columns of the
+//      matrix; the kw pivot rows Q = W[pivrow[k0..], :] are snapshotted to a scratch area.
+//   3. TRAILING UPDATE on the matrix cores (all 8 waves), in place:
 //         W[i][J] = (i pivot row of this panel ? 0 : W[i][J]) + P[i][:] * Q[:][J]
-//      Work item = (row tile I, chunk of 4 column tiles): the P fragments of I are
-//      fetched once (L2-hot: just written by this CU), then per column tile the Q
-//      fragments and the C tile; a 16x16 complex tile = 4 real v_mfma_f64_16x16x4_f64
-//      chains per 4-deep k-step (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
+//      Work item = (column tile J, half of the row tiles): Q fragments of J in registers,
+//      row tiles swept with the next C tile prefetched; a 16x16 complex tile = 4 real
+//      v_mfma_f64_16x16x4_f64 chains per 4-deep k-step
+//      (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
 // Flops: 8 n^3 per matrix (complex MAC = 8) -- the LU + triangular-inversion optimum.
 // Ties in the pivot search are broken by the lower physical row index (LAPACK: lower
 // logical index); this only matters for exactly equal |.|_1 values.
@@ -48,18 +46,16 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int MAX_WAVES = 16;
+constexpr int GJB_THREADS = 512;
+constexpr int GJB_WAVES = GJB_THREADS / 64;
+constexpr int PW = 4;                              // panel waves
+constexpr int PT = PW * 64;                        // panel threads = rows per pass
 
-template <int T, int NB, int CPR, int RPT>
+template <int NB, int RPT>
 struct GjCfg {
-    static constexpr int THREADS = T;
-    static constexpr int WAVES = T / 64;
-    static constexpr int S = NB / CPR;             // complex values per strip
-    static constexpr int TPR = T / CPR;            // threads along the row dimension
-    static constexpr int ROWS = TPR * RPT;         // row capacity
-    static constexpr int WPG = WAVES / CPR;        // waves per column part (owner group size)
-    static constexpr int PITCH = NB + 1;           // LDS row pitch of P in complex (odd -> conflict free)
-    static constexpr int RS = (WAVES >= 16) ? 4 : 2;   // row splits of a column tile in the update
+    static constexpr int S = NB;                   // complex values per strip (a full panel row)
+    static constexpr int ROWS = PT * RPT;          // row capacity
+    static constexpr int RS = 2;                   // row splits of a column tile in the update
 };
 
 struct RedSlot { double v; int key; int pad; };
@@ -103,202 +99,200 @@ __device__ __forceinline__ void wave_argmax(double& v, int& key)
 constexpr int KEY_NONE = 0x7fffffff;
 
 // ---- one Gauss-Jordan column step on the register strips, J known at compile time ----
-template <int T, int NB, int CPR, int RPT>
+template <int NB, int RPT>
 struct PanelCtx {
-    cplx (&a)[RPT][NB / CPR];
+    cplx (&a)[RPT][NB];
     bool (&avail)[RPT];              // row not used as a pivot yet
     cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh;
     int* pivrow; int* colof;
-    int n, k0, kw, tid, lane, wave, h, tr, wave_tr0;
+    int n, k0, kw, tid, lane, wave, wave_tr0;
+    bool active;                     // this wave holds strips (waves >= PW only take the barriers)
 };
 
-template <int T, int NB, int CPR, int RPT, int J>
+template <int NB, int RPT, int J>
 struct PanelSteps {
-    static __device__ __forceinline__ void run(PanelCtx<T, NB, CPR, RPT>& x)
+    static __device__ __forceinline__ void run(PanelCtx<NB, RPT>& x)
     {
-        using C = GjCfg<T, NB, CPR, RPT>;
-        constexpr int S = C::S, TPR = C::TPR, WPG = C::WPG;
-        constexpr int hj = J / S, sj = J % S;
+        constexpr int S = NB;
         if (J < x.kw) {                                     // uniform branch
             const int c = x.k0 + J;
-            // (1) combine the partials published by the waves that own column J
-            const RedSlot* red = x.red + (J & 1) * MAX_WAVES + hj * WPG;
-            double wv = red[0].v; int pphys = red[0].key;
+            int pphys = KEY_NONE;
+            if (x.active) {
+                // (1) combine the partials published by the panel waves
+                const RedSlot* red = x.red + (J & 1) * PW;
+                double wv = red[0].v; pphys = red[0].key;
 #pragma unroll
-            for (int w = 1; w < WPG; ++w) {
-                const double ov = red[w].v; const int ok = red[w].key;
-                const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
-                wv = take ? ov : wv; pphys = take ? ok : pphys;
-            }
-            if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // exactly singular / NaN
-            // a column of NaNs yields no candidate: fall back to any still-available row so the
-            // bookkeeping stays a permutation (the result is NaN anyway and info is set)
-            if (pphys == KEY_NONE) {
-                int cand = KEY_NONE;
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int r = x.tr + q * TPR;
-                    if (x.h == 0 && r < x.n && x.avail[q]) cand = min(cand, r);
+                for (int w = 1; w < PW; ++w) {
+                    const double ov = red[w].v; const int ok = red[w].key;
+                    const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
+                    wv = take ? ov : wv; pphys = take ? ok : pphys;
                 }
-                double dv = 0.0;
-                int k2 = cand;
-                // min over the workgroup via the same machinery (negated key trick not needed: use LDS)
-                __syncthreads();
+                if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // singular / NaN
+            }
+            // a column of NaNs yields no candidate: fall back to the lowest still-available row so
+            // the bookkeeping stays a permutation (the result is NaN anyway and info is set)
+            if (__syncthreads_or(x.active && pphys == KEY_NONE)) {
                 if (x.tid == 0) x.red[0].pad = KEY_NONE;
                 __syncthreads();
-                if (k2 != KEY_NONE) atomicMin(&x.red[0].pad, k2);
+                if (x.active) {
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const int r = x.tid + q * PT;
+                        if (r < x.n && x.avail[q]) atomicMin(&x.red[0].pad, r);
+                    }
+                }
                 __syncthreads();
                 pphys = x.red[0].pad;
-                (void)dv;
             }
-            // (2) publish the unscaled pivot row, 1/pivot and the pivot column
+            if (x.active) {
+                // (2) publish the unscaled pivot row, 1/pivot and the pivot column
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = x.tr + q * TPR;
-                if (r == pphys) {
+                for (int q = 0; q < RPT; ++q) {
+                    const int r = x.tid + q * PT;
+                    if (r == pphys) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) x.rowbuf[x.h * S + s] = x.a[q][s];
-                    if (x.h == hj) {
+                        for (int s = 0; s < S; ++s) x.rowbuf[s] = x.a[q][s];
                         // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
                         // overflow range for these matrices)
-                        const cplx pv = x.a[q][sj];
+                        const cplx pv = x.a[q][J];
                         const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
                         *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
                     }
+                    x.colbuf[r] = x.a[q][J];
                 }
-                if (x.h == hj) x.colbuf[r] = x.a[q][sj];
+                if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
             }
-            if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
             __syncthreads();
-            // (3) rank-1 update of every strip in two half-strips (bounded register use): a batch of
-            //     LDS reads of the pivot row part, then register arithmetic
-            const cplx ip = *x.piv_ip;
-            cplx nfm[RPT];
+            if (x.active) {
+                // (3) rank-1 update of every strip in two half-strips (bounded register use): a batch
+                //     of LDS reads of the pivot row part, then register arithmetic
+                const cplx ip = *x.piv_ip;
+                cplx nfm[RPT];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tr + q * TPR], ip));   // -(f / pivot)
-            bool wave_has_piv = false;
+                for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tid + q * PT], ip));   // -(f / pivot)
+                bool wave_has_piv = false;
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int d = pphys - q * TPR - x.wave_tr0;
-                wave_has_piv |= (d >= 0 && d < 64);
-            }
-            constexpr int HS = (S >= 8) ? S / 2 : S;        // half-strip length
+                for (int q = 0; q < RPT; ++q) {
+                    const int d = pphys - q * PT - x.wave_tr0;
+                    wave_has_piv |= (d >= 0 && d < 64);
+                }
+                constexpr int HS = (S >= 8) ? 8 : S;            // sub-strip length (bounds register use)
 #pragma unroll
-            for (int s0 = 0; s0 < S; s0 += HS) {
-                cplx rb[HS];
+                for (int s0 = 0; s0 < S; s0 += HS) {
+                    cplx rb[HS];
 #pragma unroll
-                for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[x.h * S + s0 + s];
-                if (!wave_has_piv) {
-                    // select-free path: row <- row - (f/pivot) * pivot row
+                    for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[s0 + s];
+                    if (!wave_has_piv) {
+                        // select-free path: row <- row - (f/pivot) * pivot row
 #pragma unroll
-                    for (int q = 0; q < RPT; ++q)
+                        for (int q = 0; q < RPT; ++q)
 #pragma unroll
-                        for (int s = 0; s < HS; ++s) x.a[q][s0 + s] = cfma(x.a[q][s0 + s], nfm[q], rb[s]);
-                } else {
-                    // the wave holding the pivot row: that row becomes (pivot row) / pivot
+                            for (int s = 0; s < HS; ++s) x.a[q][s0 + s] = cfma(x.a[q][s0 + s], nfm[q], rb[s]);
+                    } else {
+                        // the wave holding the pivot row: that row becomes (pivot row) / pivot
 #pragma unroll
-                    for (int q = 0; q < RPT; ++q) {
-                        const bool is_piv = (x.tr + q * TPR) == pphys;
-                        const cplx coef = is_piv ? ip : nfm[q];
+                        for (int q = 0; q < RPT; ++q) {
+                            const bool is_piv = (x.tid + q * PT) == pphys;
+                            const cplx coef = is_piv ? ip : nfm[q];
 #pragma unroll
-                        for (int s = 0; s < HS; ++s) {
-                            const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s0 + s];
-                            x.a[q][s0 + s] = cfma(base, coef, rb[s]);
+                            for (int s = 0; s < HS; ++s) {
+                                const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s0 + s];
+                                x.a[q][s0 + s] = cfma(base, coef, rb[s]);
+                            }
                         }
                     }
                 }
-            }
-            // pivot-column entry: 1/pivot on the pivot row, -(f/pivot) elsewhere
+                // pivot-column entry: 1/pivot on the pivot row, -(f/pivot) elsewhere
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const bool is_piv = (x.tr + q * TPR) == pphys;
-                if (x.h == hj) x.a[q][sj] = is_piv ? ip : nfm[q];
-                x.avail[q] = x.avail[q] && !is_piv;
-            }
-            // (4) pivot search for column J+1 on the freshly updated strips (owner waves only)
-            if constexpr (J + 1 < NB) {
-                constexpr int hn = (J + 1) / S, sn = (J + 1) % S;
-                if (x.h == hn && J + 1 < x.kw) {            // wave-uniform: a wave belongs to one column part
-                    double bv = -1.0; int bkey = KEY_NONE;
+                for (int q = 0; q < RPT; ++q) {
+                    const bool is_piv = (x.tid + q * PT) == pphys;
+                    x.a[q][J] = is_piv ? ip : nfm[q];
+                    x.avail[q] = x.avail[q] && !is_piv;
+                }
+                // (4) pivot search for column J+1 on the freshly updated strips
+                if constexpr (J + 1 < NB) {
+                    if (J + 1 < x.kw) {
+                        double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
-                    for (int q = 0; q < RPT; ++q) {
-                        const int r = x.tr + q * TPR;
-                        if (r < x.n && x.avail[q]) {
-                            const double v = cabs1(x.a[q][sn]);
-                            const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                            bv = take ? v : bv; bkey = take ? r : bkey;
+                        for (int q = 0; q < RPT; ++q) {
+                            const int r = x.tid + q * PT;
+                            if (r < x.n && x.avail[q]) {
+                                const double v = cabs1(x.a[q][J + 1]);
+                                const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                                bv = take ? v : bv; bkey = take ? r : bkey;
+                            }
                         }
+                        wave_argmax(bv, bkey);
+                        RedSlot* rn = x.red + ((J + 1) & 1) * PW;
+                        if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
                     }
-                    wave_argmax(bv, bkey);
-                    RedSlot* rn = x.red + ((J + 1) & 1) * MAX_WAVES;
-                    if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
                 }
             }
             __syncthreads();
-            if constexpr (J + 1 < NB) PanelSteps<T, NB, CPR, RPT, J + 1>::run(x);
+            if constexpr (J + 1 < NB) PanelSteps<NB, RPT, J + 1>::run(x);
         }
     }
 };
 
-template <int T, int NB, int CPR, int RPT>
-__global__ __launch_bounds__(T) void gj_blocked_kernel(
+template <int NB, int RPT>
+__global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
     int dbg /* ablation switches, 0 in production: 1 = no pivot steps, 2 = no MFMA, 4 = no tile loads */)
 {
-    using C = GjCfg<T, NB, CPR, RPT>;
-    constexpr int S = C::S, TPR = C::TPR, PITCH = C::PITCH, RS = C::RS;
-    constexpr int GJB_THREADS = T, GJB_WAVES = C::WAVES;
+    using C = GjCfg<NB, RPT>;
+    constexpr int S = C::S, RS = C::RS;
     constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int rows16 = (n + 15) & ~15;
-    cplx* P = reinterpret_cast<cplx*>(smem_raw);                 // [rows16][PITCH]  physical rows
-    cplx* rowbuf = P + (size_t)rows16 * PITCH;                   // [NB]   unscaled pivot row
+    cplx* Pt = reinterpret_cast<cplx*>(smem_raw);                // [NB][rows16]  P, k-major, physical rows
+    cplx* rowbuf = Pt + (size_t)NB * rows16;                     // [NB]   unscaled pivot row
     cplx* colbuf = rowbuf + NB;                                  // [ROWS] pivot column
     int* pivrow = reinterpret_cast<int*>(colbuf + C::ROWS);      // [rows16] physical pivot row of column c
     int* colof = pivrow + rows16;                                // [rows16] column a row was pivot for, or -1
-    __shared__ RedSlot red[2][MAX_WAVES];
+    __shared__ RedSlot red[2][PW];
     __shared__ cplx piv_ip;
     __shared__ int bad_sh;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = tid / TPR;                 // column part of the panel held by this thread (wave-uniform)
-    const int tr = tid - h * TPR;            // row slot
-    const int wave_tr0 = (tid & ~63) - h * TPR;
+    const bool pwave = wave < PW;
     cplx* W = bufA + (size_t)blockIdx.x * mat_stride;            // the matrix, updated in place
     cplx* X = bufB + (size_t)blockIdx.x * mat_stride;            // Q snapshots, then the result
 
     if (tid == 0) bad_sh = 0;
     for (int t = tid; t < rows16; t += GJB_THREADS) { colof[t] = -1; pivrow[t] = 0; }
-
     // rows >= n of P stay zero for the whole kernel (A operand of the edge tiles)
-    for (int t = tid; t < (rows16 - n) * PITCH; t += GJB_THREADS) P[(size_t)n * PITCH + t] = cmake(0.0, 0.0);
+    for (int t = tid; t < NB * (rows16 - n); t += GJB_THREADS) {
+        const int k = t / (rows16 - n), r = n + t - k * (rows16 - n);
+        Pt[(size_t)k * rows16 + r] = cmake(0.0, 0.0);
+    }
 
     const int fi = lane & 15, fk = lane >> 4;
     const int tiles = rows16 >> 4;
 
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int kw = min(NB, n - k0);
-        __syncthreads();                 // previous trailing update (stores to W, reads of P/colof) is complete
-        // ---------------- panel: global -> register strips.  Every thread fetches its own strip
-        // (S independent 16-byte loads issued back to back: one memory latency per panel)
+        __syncthreads();                 // previous trailing update (stores to W, reads of Pt/colof) is complete
+        // ---------------- panel: global -> register strips.  Every panel thread fetches its own
+        // strip(s): NB independent 16-byte loads issued back to back, one memory latency per panel
         cplx a[RPT][S];
         bool avail[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int r = tr + q * TPR;
-            avail[q] = (r < n) && (colof[r < rows16 ? r : 0] < 0);
-            const cplx* g = W + (size_t)(r < n ? r : 0) * n + k0 + h * S;
+            const int r = tid + q * PT;
+            const bool row_ok = pwave && r < n;
+            avail[q] = row_ok && (colof[r < rows16 ? r : 0] < 0);
+            const cplx* g = W + (size_t)(row_ok ? r : 0) * n + k0;
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                a[q][s] = (r < n && h * S + s < kw) ? g[s] : cmake(0.0, 0.0);
+                a[q][s] = (row_ok && s < kw) ? g[s] : cmake(0.0, 0.0);
         }
-        // ---------------- pivot search for the first column of the panel (waves holding column part 0)
-        if (!(dbg & 1) && h == 0) {
+        // ---------------- pivot search for the first column of the panel
+        if (!(dbg & 1) && pwave) {
             double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int r = tr + q * TPR;
+                const int r = tid + q * PT;
                 if (r < n && avail[q]) {
                     const double v = cabs1(a[q][0]);
                     const bool take = (v > bv) | ((v == bv) & (r < bkey));
@@ -312,34 +306,37 @@ __global__ __launch_bounds__(T) void gj_blocked_kernel(
         // ---------------- kw Gauss-Jordan column steps on the register strips
         // (compile-time recursion over the panel column: every strip index is a constant)
         if (!(dbg & 1)) {
-            PanelCtx<T, NB, CPR, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
-                                       n, k0, kw, tid, lane, wave, h, tr, wave_tr0};
-            PanelSteps<T, NB, CPR, RPT, 0>::run(ctx);
-        } else if (tid == 0) {
-            for (int j = 0; j < kw; ++j) { pivrow[k0 + j] = k0 + j; colof[k0 + j] = k0 + j; }
+            PanelCtx<NB, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
+                                  n, k0, kw, tid, lane, wave, tid & ~63, pwave};
+            PanelSteps<NB, RPT, 0>::run(ctx);
+        } else {
+            if (tid == 0) for (int j = 0; j < kw; ++j) { pivrow[k0 + j] = k0 + j; colof[k0 + j] = k0 + j; }
+            __syncthreads();
         }
-        // ---------------- strips -> panel columns of the matrix (P, physical rows) ; pivot rows ->
-        // Q snapshot X[k][:].  pivrow[] of this panel was written before the last barrier of the
-        // pivot steps, so it is visible here.
-        if (dbg & 1) __syncthreads();
+        // ---------------- strips -> panel columns of the matrix and -> Pt (LDS, k-major: lanes of a
+        // wave write consecutive rows -> contiguous, conflict-free)
+        if (pwave) {
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = tr + q * TPR;
-            if (r < n) {
-                cplx* g = W + (size_t)r * n + k0 + h * S;
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + q * PT;
+                if (r < n) {
+                    cplx* g = W + (size_t)r * n + k0;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (h * S + s < kw) g[s] = a[q][s];
-                    P[(size_t)r * PITCH + h * S + s] = a[q][s];
+                    for (int s = 0; s < S; ++s) {
+                        if (s < kw) g[s] = a[q][s];
+                        Pt[(size_t)s * rows16 + r] = a[q][s];
+                    }
                 }
             }
         }
+        // ---------------- pivot rows -> Q snapshot X[k][:]  (pivrow[] of this panel was published
+        // before the last barrier of the pivot steps)
         for (int k = wave; k < kw; k += GJB_WAVES) {
             const cplx* srow = W + (size_t)pivrow[k0 + k] * n;
             cplx* drow = X + (size_t)k * n;
             for (int j = lane; j < n; j += 64) drow[j] = srow[j];
         }
-        __syncthreads();                 // Q snapshot visible; nobody reads a pivot row of W after this point
+        __syncthreads();                 // Pt, Q snapshot visible; nobody reads a pivot row of W after this
         // ---------------- trailing update (in place)
         // column tiles fully inside the panel are skipped; a tile that only touches it
         // (NB = 8, or the ragged last panel) is computed and its panel columns masked
@@ -383,11 +380,11 @@ __global__ __launch_bounds__(T) void gj_blocked_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { accr[r] = c0[r].x; acci[r] = c0[r].y; }
                 load_c(ti + 1, c0);
-                const cplx* prow = P + (size_t)(ti * 16 + fi) * PITCH + fk;
+                const cplx* pcol = Pt + (size_t)fk * rows16 + ti * 16 + fi;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (ks * 4 < kw) {
-                        const cplx pa = prow[ks * 4];
+                        const cplx pa = pcol[(size_t)ks * 4 * rows16];
                         if (dbg & 2) { accr[0] += pa.x * qf[ks].x; acci[0] += pa.y * qf[ks].y; continue; }
                         accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
                         accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
@@ -428,28 +425,28 @@ __global__ __launch_bounds__(T) void gj_blocked_kernel(
     }
 }
 
-template <int T, int NB, int CPR, int RPT>
+template <int NB, int RPT>
 size_t gj_smem(int n)
 {
-    using C = GjCfg<T, NB, CPR, RPT>;
+    using C = GjCfg<NB, RPT>;
     const size_t rows16 = (size_t)((n + 15) & ~15);
-    return rows16 * C::PITCH * sizeof(cplx) + NB * sizeof(cplx) + (size_t)C::ROWS * sizeof(cplx) +
+    return (size_t)NB * rows16 * sizeof(cplx) + NB * sizeof(cplx) + (size_t)C::ROWS * sizeof(cplx) +
            2 * rows16 * sizeof(int);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;      // static __shared__ of the kernel is < 1 KB
 
-template <int T, int NB, int CPR, int RPT>
+template <int NB, int RPT>
 bool gj_fits(int n)
 {
-    return n <= GjCfg<T, NB, CPR, RPT>::ROWS && gj_smem<T, NB, CPR, RPT>(n) <= LDS_LIMIT;
+    return n <= GjCfg<NB, RPT>::ROWS && gj_smem<NB, RPT>(n) <= LDS_LIMIT;
 }
 
-template <int T, int NB, int CPR, int RPT>
+template <int NB, int RPT>
 void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
-    auto kern = gj_blocked_kernel<T, NB, CPR, RPT>;
-    const size_t smem = gj_smem<T, NB, CPR, RPT>(n);
+    auto kern = gj_blocked_kernel<NB, RPT>;
+    const size_t smem = gj_smem<NB, RPT>(n);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -458,24 +455,16 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
     }
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("NEGF_GJ_DEBUG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(T), smem, st, n, A, B, stride, info, dbg);
-}
-
-int gj_variant()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("NEGF_GJ_VARIANT"); v = e ? atoi(e) : 0; }
-    return v;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg);
 }
 
 // which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
 int gj_pick(int n)
 {
     if (n < 32) return 0;                               // small matrices: the unblocked kernel
-    if (gj_variant() == 1 && gj_fits<512, 32, 2, 1>(n)) return 4;      // 8-wave variant (A/B testing)
-    if (gj_fits<1024, 32, 4, 1>(n)) return 1;           // n <= 256, panel 32, 16 waves
-    if (gj_fits<1024, 16, 2, 1>(n)) return 2;           // n <= 512, panel 16
-    if (gj_fits<1024, 8, 1, 1>(n)) return 3;            // n <= ~900, panel 8
+    if (gj_fits<32, 1>(n)) return 1;                    // n <= 256, panel 32
+    if (gj_fits<16, 2>(n)) return 2;                    // n <= 512, panel 16
+    if (gj_fits<8, 4>(n)) return 3;                     // n <= ~960, panel 8
     return 0;
 }
 
@@ -488,10 +477,9 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0; }
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
     switch (gj_pick(n)) {
-    case 1: gj_launch<1024, 32, 4, 1>(st, n, nb, A, B, stride, info); break;
-    case 2: gj_launch<1024, 16, 2, 1>(st, n, nb, A, B, stride, info); break;
-    case 3: gj_launch<1024, 8, 1, 1>(st, n, nb, A, B, stride, info); break;
-    case 4: gj_launch<512, 32, 2, 1>(st, n, nb, A, B, stride, info); break;
+    case 1: gj_launch<32, 1>(st, n, nb, A, B, stride, info); break;
+    case 2: gj_launch<16, 2>(st, n, nb, A, B, stride, info); break;
+    case 3: gj_launch<8, 4>(st, n, nb, A, B, stride, info); break;
     default: return false;
     }
     return true;
