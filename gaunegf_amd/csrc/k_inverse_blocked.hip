@@ -1,5 +1,5 @@
-// Blocked Gauss-Jordan inversion with partial pivoting, FP64 MFMA trailing updates,
-// one workgroup (512 threads, 8 waves) per matrix.   gfx950 / MI355X.
+// Blocked Gauss-Jordan inversion with partial pivoting, FP64 MFMA trailing updates and
+// panel LOOK-AHEAD, one workgroup (512 threads, 8 waves) per matrix.   gfx950 / MI355X.
 //
 // Replaces G = solve(E S - F - Sigma, I)  (gauNEGF/integrate.py:71, utils.py:52-54,
 // transport.py:154,163,186) for every energy point of the grid.
@@ -13,26 +13,26 @@
 // Keeping every row at its address makes each 16x16 tile update a pure
 // read-modify-write by one wave.
 //
-// Per block column K = [k0, k0+kw), kw <= NB:
-//   1. PANEL (waves 0..PW-1).  The n x kw panel lives in REGISTERS, one full row strip
+// Block column K = [k0, k0+kw), kw <= NB.  Two teams of four waves:
+//   P-team (waves 0-3): PANEL.  The n x kw panel lives in REGISTERS, one full row strip
 //      (NB complex128) per thread.  kw unblocked Gauss-Jordan column steps with partial
 //      pivoting (|re|+|im| as LAPACK izamax; among not-yet-used rows) run on the strips;
 //      only the pivot row, the pivot column and the per-wave arg-max partials go through
-//      LDS: two barriers per column step, the search for column j+1 is fused into the
-//      update of column j, the wave arg-max uses DPP lane moves, and waves that do not
-//      hold the pivot row run a select-free update.  The phase is VALU-issue bound
-//      (PMC: ~170 vector instructions per wave per step), so it runs on the FEWEST waves
-//      that can hold the panel: the per-wave bookkeeping is not replicated 8 or 16 times.
-//      Result: the block column of the elementary transform M_K, i.e.
-//      P = [ -A0K AKK^-1 ; AKK^-1 ; -A2K AKK^-1 ]  (physical rows).
-//   2. P -> LDS, k-major (conflict-free A-operand reads), and -> the panel columns of the
-//      matrix; the kw pivot rows Q = W[pivrow[k0..], :] are snapshotted to a scratch area.
-//   3. TRAILING UPDATE on the matrix cores (all 8 waves), in place:
-//         W[i][J] = (i pivot row of this panel ? 0 : W[i][J]) + P[i][:] * Q[:][J]
-//      Work item = (column tile J, half of the row tiles): Q fragments of J in registers,
-//      row tiles swept with the next C tile prefetched; a 16x16 complex tile = 4 real
+//      LDS; the search for column j+1 is fused into the update of column j, the wave
+//      arg-max uses DPP lane moves, waves that do not hold the pivot row run a
+//      select-free update.  The phase is a latency chain (two team barriers per column),
+//      so it runs CONCURRENTLY with the update of the previous block column:
+//   U-team (waves 4-7): TRAILING UPDATE of step k on the matrix cores, in place:
+//         W[i][J] = (i pivot row of panel k ? 0 : W[i][J]) + P_k[i][:] * Q_k[:][J]
+//      with P_k in LDS (k-major, conflict-free A-operand reads), the Q_k fragments of a
+//      column tile in registers, C tiles prefetched; a 16x16 complex tile = 4 real
 //      v_mfma_f64_16x16x4_f64 chains per 4-deep k-step
 //      (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
+//   Look-ahead: at step k the P-team first applies step k to the columns of panel k+1
+//      (a few tiles), then factors panel k+1 in registers while the U-team updates all
+//      other columns.  The teams meet at a workgroup barrier; the strips of panel k+1
+//      then become P_{k+1} in LDS and the pivot rows are snapshotted as Q_{k+1}.
+//      Team barriers are LDS counters (gfx950 has one hardware barrier per workgroup).
 // Flops: 8 n^3 per matrix (complex MAC = 8) -- the LU + triangular-inversion optimum.
 // Ties in the pivot search are broken by the lower physical row index (LAPACK: lower
 // logical index); this only matters for exactly equal |.|_1 values.
@@ -48,17 +48,28 @@ namespace {
 
 constexpr int GJB_THREADS = 512;
 constexpr int GJB_WAVES = GJB_THREADS / 64;
-constexpr int PW = 4;                              // panel waves
+constexpr int PW = 4;                              // panel-team waves
 constexpr int PT = PW * 64;                        // panel threads = rows per pass
+constexpr int UW = GJB_WAVES - PW;                 // update-team waves
 
 template <int NB, int RPT>
 struct GjCfg {
     static constexpr int S = NB;                   // complex values per strip (a full panel row)
     static constexpr int ROWS = PT * RPT;          // row capacity
-    static constexpr int RS = 2;                   // row splits of a column tile in the update
 };
 
 struct RedSlot { double v; int key; int pad; };
+
+// ---- team barrier: an LDS counter (monotonic), release/acquire at workgroup scope ----
+__device__ __forceinline__ void team_sync(int* ctr, int& expect, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    expect += PW;
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect)
+        __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // ---- wave-level arg-max of (v, key): larger v wins, ties -> smaller key -------------
 // DPP lane moves inside each row of 16 lanes (xor 1, xor 2, half mirror, mirror), then
@@ -98,15 +109,14 @@ __device__ __forceinline__ void wave_argmax(double& v, int& key)
 
 constexpr int KEY_NONE = 0x7fffffff;
 
-// ---- one Gauss-Jordan column step on the register strips, J known at compile time ----
+// ---- one Gauss-Jordan column step on the register strips (P-team only), J compile-time ----
 template <int NB, int RPT>
 struct PanelCtx {
     cplx (&a)[RPT][NB];
     bool (&avail)[RPT];              // row not used as a pivot yet
     cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh;
-    int* pivrow; int* colof;
+    int* pivrow; int* colof; int* team_ctr; int& team_expect;
     int n, k0, kw, tid, lane, wave, wave_tr0;
-    bool active;                     // this wave holds strips (waves >= PW only take the barriers)
 };
 
 template <int NB, int RPT, int J>
@@ -116,119 +126,111 @@ struct PanelSteps {
         constexpr int S = NB;
         if (J < x.kw) {                                     // uniform branch
             const int c = x.k0 + J;
-            int pphys = KEY_NONE;
-            if (x.active) {
-                // (1) combine the partials published by the panel waves
-                const RedSlot* red = x.red + (J & 1) * PW;
-                double wv = red[0].v; pphys = red[0].key;
+            // (1) combine the partials published by the panel waves
+            const RedSlot* red = x.red + (J & 1) * PW;
+            double wv = red[0].v; int pphys = red[0].key;
 #pragma unroll
-                for (int w = 1; w < PW; ++w) {
-                    const double ov = red[w].v; const int ok = red[w].key;
-                    const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
-                    wv = take ? ov : wv; pphys = take ? ok : pphys;
-                }
-                if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // singular / NaN
+            for (int w = 1; w < PW; ++w) {
+                const double ov = red[w].v; const int ok = red[w].key;
+                const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
+                wv = take ? ov : wv; pphys = take ? ok : pphys;
             }
-            // a column of NaNs yields no candidate: fall back to the lowest still-available row so
-            // the bookkeeping stays a permutation (the result is NaN anyway and info is set)
-            if (__syncthreads_or(x.active && pphys == KEY_NONE)) {
+            if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // singular / NaN
+            // a column of NaNs yields no candidate (the same for every wave of the team): fall back
+            // to the lowest still-available row so the bookkeeping stays a permutation
+            if (pphys == KEY_NONE) {
                 if (x.tid == 0) x.red[0].pad = KEY_NONE;
-                __syncthreads();
-                if (x.active) {
-#pragma unroll
-                    for (int q = 0; q < RPT; ++q) {
-                        const int r = x.tid + q * PT;
-                        if (r < x.n && x.avail[q]) atomicMin(&x.red[0].pad, r);
-                    }
-                }
-                __syncthreads();
-                pphys = x.red[0].pad;
-            }
-            if (x.active) {
-                // (2) publish the unscaled pivot row, 1/pivot and the pivot column
+                team_sync(x.team_ctr, x.team_expect, x.lane);
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) {
                     const int r = x.tid + q * PT;
-                    if (r == pphys) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) x.rowbuf[s] = x.a[q][s];
-                        // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
-                        // overflow range for these matrices)
-                        const cplx pv = x.a[q][J];
-                        const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
-                        *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
-                    }
-                    x.colbuf[r] = x.a[q][J];
+                    if (r < x.n && x.avail[q]) atomicMin(&x.red[0].pad, r);
                 }
-                if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
+                team_sync(x.team_ctr, x.team_expect, x.lane);
+                pphys = x.red[0].pad;
+                team_sync(x.team_ctr, x.team_expect, x.lane);
             }
-            __syncthreads();
-            if (x.active) {
-                // (3) rank-1 update of every strip in two half-strips (bounded register use): a batch
-                //     of LDS reads of the pivot row part, then register arithmetic
-                const cplx ip = *x.piv_ip;
-                cplx nfm[RPT];
+            // (2) publish the unscaled pivot row, 1/pivot and the pivot column
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tid + q * PT], ip));   // -(f / pivot)
-                bool wave_has_piv = false;
+            for (int q = 0; q < RPT; ++q) {
+                const int r = x.tid + q * PT;
+                if (r == pphys) {
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int d = pphys - q * PT - x.wave_tr0;
-                    wave_has_piv |= (d >= 0 && d < 64);
+                    for (int s = 0; s < S; ++s) x.rowbuf[s] = x.a[q][s];
+                    // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
+                    // overflow range for these matrices)
+                    const cplx pv = x.a[q][J];
+                    const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+                    *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
                 }
-                constexpr int HS = (S >= 8) ? 8 : S;            // sub-strip length (bounds register use)
+                x.colbuf[r] = x.a[q][J];
+            }
+            if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
+            team_sync(x.team_ctr, x.team_expect, x.lane);
+            // (3) rank-1 update of every strip in sub-strips of 8 (bounded register use): a batch
+            //     of LDS reads of the pivot row part, then register arithmetic
+            const cplx ip = *x.piv_ip;
+            cplx nfm[RPT];
 #pragma unroll
-                for (int s0 = 0; s0 < S; s0 += HS) {
-                    cplx rb[HS];
+            for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tid + q * PT], ip));   // -(f / pivot)
+            bool wave_has_piv = false;
 #pragma unroll
-                    for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[s0 + s];
-                    if (!wave_has_piv) {
-                        // select-free path: row <- row - (f/pivot) * pivot row
+            for (int q = 0; q < RPT; ++q) {
+                const int d = pphys - q * PT - x.wave_tr0;
+                wave_has_piv |= (d >= 0 && d < 64);
+            }
+            constexpr int HS = (S >= 8) ? 8 : S;
 #pragma unroll
-                        for (int q = 0; q < RPT; ++q)
+            for (int s0 = 0; s0 < S; s0 += HS) {
+                cplx rb[HS];
 #pragma unroll
-                            for (int s = 0; s < HS; ++s) x.a[q][s0 + s] = cfma(x.a[q][s0 + s], nfm[q], rb[s]);
-                    } else {
-                        // the wave holding the pivot row: that row becomes (pivot row) / pivot
+                for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[s0 + s];
+                if (!wave_has_piv) {
+                    // select-free path: row <- row - (f/pivot) * pivot row
 #pragma unroll
-                        for (int q = 0; q < RPT; ++q) {
-                            const bool is_piv = (x.tid + q * PT) == pphys;
-                            const cplx coef = is_piv ? ip : nfm[q];
+                    for (int q = 0; q < RPT; ++q)
 #pragma unroll
-                            for (int s = 0; s < HS; ++s) {
-                                const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s0 + s];
-                                x.a[q][s0 + s] = cfma(base, coef, rb[s]);
-                            }
+                        for (int s = 0; s < HS; ++s) x.a[q][s0 + s] = cfma(x.a[q][s0 + s], nfm[q], rb[s]);
+                } else {
+                    // the wave holding the pivot row: that row becomes (pivot row) / pivot
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const bool is_piv = (x.tid + q * PT) == pphys;
+                        const cplx coef = is_piv ? ip : nfm[q];
+#pragma unroll
+                        for (int s = 0; s < HS; ++s) {
+                            const cplx base = is_piv ? cmake(0.0, 0.0) : x.a[q][s0 + s];
+                            x.a[q][s0 + s] = cfma(base, coef, rb[s]);
                         }
                     }
                 }
-                // pivot-column entry: 1/pivot on the pivot row, -(f/pivot) elsewhere
+            }
+            // pivot-column entry: 1/pivot on the pivot row, -(f/pivot) elsewhere
 #pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const bool is_piv = (x.tid + q * PT) == pphys;
-                    x.a[q][J] = is_piv ? ip : nfm[q];
-                    x.avail[q] = x.avail[q] && !is_piv;
-                }
-                // (4) pivot search for column J+1 on the freshly updated strips
-                if constexpr (J + 1 < NB) {
-                    if (J + 1 < x.kw) {
-                        double bv = -1.0; int bkey = KEY_NONE;
+            for (int q = 0; q < RPT; ++q) {
+                const bool is_piv = (x.tid + q * PT) == pphys;
+                x.a[q][J] = is_piv ? ip : nfm[q];
+                x.avail[q] = x.avail[q] && !is_piv;
+            }
+            // (4) pivot search for column J+1 on the freshly updated strips
+            if constexpr (J + 1 < NB) {
+                if (J + 1 < x.kw) {
+                    double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
-                        for (int q = 0; q < RPT; ++q) {
-                            const int r = x.tid + q * PT;
-                            if (r < x.n && x.avail[q]) {
-                                const double v = cabs1(x.a[q][J + 1]);
-                                const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                                bv = take ? v : bv; bkey = take ? r : bkey;
-                            }
+                    for (int q = 0; q < RPT; ++q) {
+                        const int r = x.tid + q * PT;
+                        if (r < x.n && x.avail[q]) {
+                            const double v = cabs1(x.a[q][J + 1]);
+                            const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                            bv = take ? v : bv; bkey = take ? r : bkey;
                         }
-                        wave_argmax(bv, bkey);
-                        RedSlot* rn = x.red + ((J + 1) & 1) * PW;
-                        if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
                     }
+                    wave_argmax(bv, bkey);
+                    RedSlot* rn = x.red + ((J + 1) & 1) * PW;
+                    if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
                 }
             }
-            __syncthreads();
+            team_sync(x.team_ctr, x.team_expect, x.lane);
             if constexpr (J + 1 < NB) PanelSteps<NB, RPT, J + 1>::run(x);
         }
     }
@@ -237,10 +239,11 @@ struct PanelSteps {
 template <int NB, int RPT>
 __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
-    int dbg /* ablation switches, 0 in production: 1 = no pivot steps, 2 = no MFMA, 4 = no tile loads */)
+    int dbg /* ablation switches, 0 in production: 2 = no MFMA, 4 = no tile loads, 16 = U-team idle,
+               32 = no pivot steps */)
 {
     using C = GjCfg<NB, RPT>;
-    constexpr int S = C::S, RS = C::RS;
+    constexpr int S = C::S;
     constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -253,154 +256,192 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     __shared__ RedSlot red[2][PW];
     __shared__ cplx piv_ip;
     __shared__ int bad_sh;
+    __shared__ int team_ctr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool pwave = wave < PW;
     cplx* W = bufA + (size_t)blockIdx.x * mat_stride;            // the matrix, updated in place
     cplx* X = bufB + (size_t)blockIdx.x * mat_stride;            // Q snapshots, then the result
+    int team_expect = 0;
 
-    if (tid == 0) bad_sh = 0;
+    if (tid == 0) { bad_sh = 0; team_ctr = 0; }
     for (int t = tid; t < rows16; t += GJB_THREADS) { colof[t] = -1; pivrow[t] = 0; }
     // rows >= n of P stay zero for the whole kernel (A operand of the edge tiles)
     for (int t = tid; t < NB * (rows16 - n); t += GJB_THREADS) {
         const int k = t / (rows16 - n), r = n + t - k * (rows16 - n);
         Pt[(size_t)k * rows16 + r] = cmake(0.0, 0.0);
     }
+    __syncthreads();
 
     const int fi = lane & 15, fk = lane >> 4;
     const int tiles = rows16 >> 4;
 
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int kw = min(NB, n - k0);
-        __syncthreads();                 // previous trailing update (stores to W, reads of Pt/colof) is complete
-        // ---------------- panel: global -> register strips.  Every panel thread fetches its own
-        // strip(s): NB independent 16-byte loads issued back to back, one memory latency per panel
+    // ---- panel factorisation of block column [p0, p0+pw) by the P-team: strips in registers,
+    // result written to the panel columns of the matrix (nobody else touches them meanwhile)
+    auto factor_panel = [&](int p0, int pw) __attribute__((always_inline)) {
         cplx a[RPT][S];
         bool avail[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int r = tid + q * PT;
-            const bool row_ok = pwave && r < n;
+            const bool row_ok = r < n;
             avail[q] = row_ok && (colof[r < rows16 ? r : 0] < 0);
-            const cplx* g = W + (size_t)(row_ok ? r : 0) * n + k0;
+            const cplx* g = W + (size_t)(row_ok ? r : 0) * n + p0;
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                a[q][s] = (row_ok && s < kw) ? g[s] : cmake(0.0, 0.0);
+                a[q][s] = (row_ok && s < pw) ? g[s] : cmake(0.0, 0.0);
         }
-        // ---------------- pivot search for the first column of the panel
-        if (!(dbg & 1) && pwave) {
-            double bv = -1.0; int bkey = KEY_NONE;
+        double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = tid + q * PT;
-                if (r < n && avail[q]) {
-                    const double v = cabs1(a[q][0]);
-                    const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                    bv = take ? v : bv; bkey = take ? r : bkey;
-                }
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + q * PT;
+            if (r < n && avail[q]) {
+                const double v = cabs1(a[q][0]);
+                const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                bv = take ? v : bv; bkey = take ? r : bkey;
             }
-            wave_argmax(bv, bkey);
-            if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
         }
-        __syncthreads();
-        // ---------------- kw Gauss-Jordan column steps on the register strips
-        // (compile-time recursion over the panel column: every strip index is a constant)
-        if (!(dbg & 1)) {
+        wave_argmax(bv, bkey);
+        if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
+        team_sync(&team_ctr, team_expect, lane);
+        if (!(dbg & 32)) {
             PanelCtx<NB, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
-                                  n, k0, kw, tid, lane, wave, tid & ~63, pwave};
+                                  &team_ctr, team_expect, n, p0, pw, tid, lane, wave, tid & ~63};
             PanelSteps<NB, RPT, 0>::run(ctx);
-        } else {
-            if (tid == 0) for (int j = 0; j < kw; ++j) { pivrow[k0 + j] = k0 + j; colof[k0 + j] = k0 + j; }
-            __syncthreads();
+        } else if (tid == 0) {
+            for (int j = 0; j < pw; ++j) { pivrow[p0 + j] = p0 + j; colof[p0 + j] = p0 + j; }
         }
-        // ---------------- strips -> panel columns of the matrix and -> Pt (LDS, k-major: lanes of a
-        // wave write consecutive rows -> contiguous, conflict-free)
-        if (pwave) {
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = tid + q * PT;
-                if (r < n) {
-                    cplx* g = W + (size_t)r * n + k0;
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + q * PT;
+            if (r < n) {
+                cplx* g = W + (size_t)r * n + p0;
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (s < kw) g[s] = a[q][s];
-                        Pt[(size_t)s * rows16 + r] = a[q][s];
-                    }
-                }
+                for (int s = 0; s < S; ++s)
+                    if (s < pw) g[s] = a[q][s];
             }
         }
-        // ---------------- pivot rows -> Q snapshot X[k][:]  (pivrow[] of this panel was published
-        // before the last barrier of the pivot steps)
-        for (int k = wave; k < kw; k += GJB_WAVES) {
-            const cplx* srow = W + (size_t)pivrow[k0 + k] * n;
-            cplx* drow = X + (size_t)k * n;
-            for (int j = lane; j < n; j += 64) drow[j] = srow[j];
+    };
+
+    // ---- trailing update of one (column tile, row-tile range) item for the panel [k0, k0+kw):
+    // stores only columns with  lo <= col < hi  XOR outside (mode): see callers
+    auto update_item = [&](int k0, int kw, int tj, int ti0, int ti1, int st_lo, int st_hi,
+                           bool inside) __attribute__((always_inline)) {
+        const int col = tj * 16 + fi;
+        const bool col_ok = col < n;
+        const bool in_rng = col >= st_lo && col < st_hi;
+        const bool col_store = col_ok && !(col >= k0 && col < k0 + kw) && (inside ? in_rng : !in_rng);
+        cplx qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 4 + fk;
+            qf[ks] = cmake(0.0, 0.0);
+            if (k < kw && col_ok && !(dbg & 4)) qf[ks] = X[(size_t)k * n + col];
         }
-        __syncthreads();                 // Pt, Q snapshot visible; nobody reads a pivot row of W after this
-        // ---------------- trailing update (in place)
-        // column tiles fully inside the panel are skipped; a tile that only touches it
-        // (NB = 8, or the ragged last panel) is computed and its panel columns masked
-        const int pt_lo = (k0 + 15) >> 4;                 // first tile fully inside [k0, k0+kw) ...
-        const int pt_hi = (k0 + kw) >> 4;                 // ... up to (excluding) this one
-        const int n_skip = max(0, pt_hi - pt_lo);
-        const int ct = tiles - n_skip;                    // column tiles to process
-        // work item = (column tile, one of RS row ranges): Q fragments in registers, P from LDS
-        const int rpart = (tiles + RS - 1) / RS;
-        for (int item = wave; item < ct * RS; item += GJB_WAVES) {
-            const int cx = item / RS, part = item - cx * RS;
-            const int tj = (n_skip > 0 && cx >= pt_lo) ? cx + n_skip : cx;
-            const int ti0 = part * rpart, ti1 = min(tiles, ti0 + rpart);
-            const int col = tj * 16 + fi;
-            const bool col_ok = col < n;
-            const bool col_store = col_ok && !(col >= k0 && col < k0 + kw);
-            cplx qf[KS];
+        // the next C tile is prefetched while the current one runs its MFMAs; rows used as
+        // pivots in this panel start from zero
+        auto load_c = [&](int ti, cplx (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fk + 4 * r;
+                dst[r] = cmake(0.0, 0.0);
+                if (ti < ti1 && i < n && col_ok && !(dbg & 4)) {
+                    const int cf = colof[i];
+                    if (!(cf >= k0 && cf < k0 + kw)) dst[r] = W[(size_t)i * n + col];
+                }
+            }
+        };
+        cplx c0[4];
+        load_c(ti0, c0);
+        for (int ti = ti0; ti < ti1; ++ti) {
+            d4 accr, acci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { accr[r] = c0[r].x; acci[r] = c0[r].y; }
+            load_c(ti + 1, c0);
+            const cplx* pcol = Pt + (size_t)fk * rows16 + ti * 16 + fi;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int k = ks * 4 + fk;
-                qf[ks] = cmake(0.0, 0.0);
-                if (k < kw && col_ok && !(dbg & 4)) qf[ks] = X[(size_t)k * n + col];
+                if (ks * 4 < kw) {
+                    const cplx pa = pcol[(size_t)ks * 4 * rows16];
+                    if (dbg & 2) { accr[0] += pa.x * qf[ks].x; acci[0] += pa.y * qf[ks].y; continue; }
+                    accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
+                    accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
+                    acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].y, acci, 0, 0, 0);
+                    acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].x, acci, 0, 0, 0);
+                }
             }
-            // the next C tile is prefetched while the current one runs its MFMAs; rows used as
-            // pivots in this panel start from zero
-            auto load_c = [&](int ti, cplx (&dst)[4]) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = ti * 16 + fk + 4 * r;
-                    dst[r] = cmake(0.0, 0.0);
-                    if (ti < ti1 && i < n && col_ok && !(dbg & 4)) {
-                        const int cf = colof[i];
-                        if (!(cf >= k0 && cf < k0 + kw)) dst[r] = W[(size_t)i * n + col];
-                    }
-                }
-            };
-            cplx c0[4];
-            load_c(ti0, c0);
-            for (int ti = ti0; ti < ti1; ++ti) {
-                d4 accr, acci;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { accr[r] = c0[r].x; acci[r] = c0[r].y; }
-                load_c(ti + 1, c0);
-                const cplx* pcol = Pt + (size_t)fk * rows16 + ti * 16 + fi;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    if (ks * 4 < kw) {
-                        const cplx pa = pcol[(size_t)ks * 4 * rows16];
-                        if (dbg & 2) { accr[0] += pa.x * qf[ks].x; acci[0] += pa.y * qf[ks].y; continue; }
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].y, acci, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].x, acci, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = ti * 16 + fk + 4 * r;
-                    if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fk + 4 * r;
+                if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
             }
         }
+    };
+
+    // ---- main loop.  Step s >= 0 applies block column s to the matrix; during step s the P-team
+    // factors block column s+1 (look-ahead).  Step -1 only factors block column 0.
+    const int npanels = (n + NB - 1) / NB;
+    for (int step = -1; step < npanels; ++step) {
+        const bool has_cur = step >= 0;
+        const int k0 = has_cur ? step * NB : 0;
+        const int kw = has_cur ? min(NB, n - k0) : 0;
+        const int n0 = (step + 1) * NB;                          // next block column
+        const bool has_next = n0 < n;
+        const int nw = has_next ? min(NB, n - n0) : 0;
+        if (has_cur) {
+            // ---------------- P_k (panel columns of W, written by the P-team) -> Pt in LDS, k-major.
+            // A thread copies a run of consecutive k of one row: 16-byte global loads of one row
+            // segment, LDS writes with consecutive lanes on consecutive rows (conflict-free).
+            constexpr int KCH = (NB >= 16) ? 16 : NB;            // k values per thread
+            constexpr int CHUNKS = NB / KCH;
+            for (int t = tid; t < rows16 * CHUNKS; t += GJB_THREADS) {
+                const int r = t % rows16, ch = t / rows16;
+                if (r < n) {
+                    const cplx* g = W + (size_t)r * n + k0 + ch * KCH;
+#pragma unroll
+                    for (int s = 0; s < KCH; ++s) {
+                        const int k = ch * KCH + s;
+                        Pt[(size_t)k * rows16 + r] = (k < kw) ? g[s] : cmake(0.0, 0.0);
+                    }
+                }
+            }
+            // ---------------- pivot rows -> Q snapshot X[k][:]
+            for (int k = wave; k < kw; k += GJB_WAVES) {
+                const cplx* srow = W + (size_t)pivrow[k0 + k] * n;
+                cplx* drow = X + (size_t)k * n;
+                for (int j = lane; j < n; j += 64) drow[j] = srow[j];
+            }
+            __syncthreads();             // [A] Pt, Q snapshot visible; pivot rows of W are not read again
+        }
+        if (pwave && has_next) {
+            // ---- P-team: apply step k to the columns of block column s+1, then factor it
+            if (has_cur) {
+                const int t_lo = n0 >> 4, t_hi = (n0 + nw + 15) >> 4;    // column tiles touching [n0, n0+nw)
+                const int nq = 4;                                        // row quarters
+                const int rq = (tiles + nq - 1) / nq;
+                for (int item = wave; item < (t_hi - t_lo) * nq; item += PW) {
+                    const int tj = t_lo + item / nq, part = item % nq;
+                    update_item(k0, kw, tj, part * rq, min(tiles, part * rq + rq), n0, n0 + nw, true);
+                }
+                team_sync(&team_ctr, team_expect, lane);
+            }
+            factor_panel(n0, nw);
+        } else if (has_cur && !((dbg & 16) && has_next)) {
+            // ---- U-team (everybody on the last step): all other column tiles
+            const int nwav = has_next ? UW : GJB_WAVES;
+            const int w0 = has_next ? wave - PW : wave;
+            const int rhalf = (tiles + 1) >> 1;
+            for (int item = w0; item < tiles * 2; item += nwav) {
+                const int tj = item >> 1, part = item & 1;
+                const int c_lo = tj * 16, c_hi = min(n, c_lo + 16);
+                if (c_lo >= k0 && c_hi <= k0 + kw) continue;                         // inside block column s
+                if (has_next && c_lo >= n0 && c_hi <= n0 + nw) continue;             // done by the P-team
+                update_item(k0, kw, tj, part ? rhalf : 0, part ? tiles : rhalf,
+                            has_next ? n0 : 0, has_next ? n0 + nw : 0, false);
+            }
+        }
+        __syncthreads();                 // [B] step complete everywhere; block column s+1 factored
     }
-    __syncthreads();
     if (tid == 0) info[blockIdx.x] = bad_sh;
     // ---------------- G[i][j] = W[pivrow[i]][colof[j]] : four rows per wave iteration,
     // up to 16 independent gathers in flight per lane
