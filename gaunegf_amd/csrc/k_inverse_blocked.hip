@@ -13,16 +13,17 @@
 // Keeping every row at its address makes each 16x16 tile update a pure
 // read-modify-write by one wave.
 //
-// Block column K = [k0, k0+kw), kw <= NB.  Two teams of four waves:
-//   P-team (waves 0-3): PANEL.  The n x kw panel lives in REGISTERS, one full row strip
-//      (NB complex128) per thread.  kw unblocked Gauss-Jordan column steps with partial
+// Block column K = [k0, k0+kw), kw <= NB.  768 threads = 12 waves (<= 168 VGPRs), two teams:
+//   P-team (waves 0-7): PANEL.  The n x kw panel lives in REGISTERS, one row strip (16
+//      complex128) per thread.  kw unblocked Gauss-Jordan column steps with partial
 //      pivoting (|re|+|im| as LAPACK izamax; among not-yet-used rows) run on the strips;
 //      only the pivot row, the pivot column and the per-wave arg-max partials go through
 //      LDS; the search for column j+1 is fused into the update of column j, the wave
 //      arg-max uses DPP lane moves, waves that do not hold the pivot row run a
 //      select-free update.  The phase is a latency chain (two team barriers per column),
 //      so it runs CONCURRENTLY with the update of the previous block column:
-//   U-team (waves 4-7): TRAILING UPDATE of step k on the matrix cores, in place:
+//   U-team (waves 8-11, joined by the P-team once its panel is done: the update items come
+//      from a shared LDS work queue): TRAILING UPDATE of step k on the matrix cores, in place:
 //         W[i][J] = (i pivot row of panel k ? 0 : W[i][J]) + P_k[i][:] * Q_k[:][J]
 //      with P_k in LDS (k-major, conflict-free A-operand reads), the Q_k fragments of a
 //      column tile in registers, C tiles prefetched; a 16x16 complex tile = 4 real
@@ -46,16 +47,17 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int GJB_THREADS = 512;
+constexpr int GJB_THREADS = 768;
 constexpr int GJB_WAVES = GJB_THREADS / 64;
-constexpr int PW = 4;                              // panel-team waves
-constexpr int PT = PW * 64;                        // panel threads = rows per pass
-constexpr int UW = GJB_WAVES - PW;                 // update-team waves
+constexpr int PW = 8;                              // panel-team waves
+constexpr int PT = PW * 64;                        // panel threads
 
-template <int NB, int RPT>
+template <int NB, int CPR, int RPT>
 struct GjCfg {
-    static constexpr int S = NB;                   // complex values per strip (a full panel row)
-    static constexpr int ROWS = PT * RPT;          // row capacity
+    static constexpr int S = NB / CPR;             // complex values per strip (1/CPR of a panel row)
+    static constexpr int TPR = PT / CPR;           // panel threads along the row dimension
+    static constexpr int ROWS = TPR * RPT;         // row capacity
+    static constexpr int WPG = PW / CPR;           // waves per column part (owner group of a column)
 };
 
 struct RedSlot { double v; int key; int pad; };
@@ -110,27 +112,29 @@ __device__ __forceinline__ void wave_argmax(double& v, int& key)
 constexpr int KEY_NONE = 0x7fffffff;
 
 // ---- one Gauss-Jordan column step on the register strips (P-team only), J compile-time ----
-template <int NB, int RPT>
+template <int NB, int CPR, int RPT>
 struct PanelCtx {
-    cplx (&a)[RPT][NB];
+    cplx (&a)[RPT][NB / CPR];
     bool (&avail)[RPT];              // row not used as a pivot yet
     cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh;
     int* pivrow; int* colof; int* team_ctr; int& team_expect;
-    int n, k0, kw, tid, lane, wave, wave_tr0;
+    int n, k0, kw, tid, lane, wave, h, tr, wave_tr0;
 };
 
-template <int NB, int RPT, int J>
+template <int NB, int CPR, int RPT, int J>
 struct PanelSteps {
-    static __device__ __forceinline__ void run(PanelCtx<NB, RPT>& x)
+    static __device__ __forceinline__ void run(PanelCtx<NB, CPR, RPT>& x)
     {
-        constexpr int S = NB;
+        using C = GjCfg<NB, CPR, RPT>;
+        constexpr int S = C::S, TPR = C::TPR, WPG = C::WPG;
+        constexpr int hj = J / S, sj = J % S;
         if (J < x.kw) {                                     // uniform branch
             const int c = x.k0 + J;
-            // (1) combine the partials published by the panel waves
-            const RedSlot* red = x.red + (J & 1) * PW;
+            // (1) combine the partials published by the waves that own column J
+            const RedSlot* red = x.red + (J & 1) * PW + hj * WPG;
             double wv = red[0].v; int pphys = red[0].key;
 #pragma unroll
-            for (int w = 1; w < PW; ++w) {
+            for (int w = 1; w < WPG; ++w) {
                 const double ov = red[w].v; const int ok = red[w].key;
                 const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
                 wv = take ? ov : wv; pphys = take ? ok : pphys;
@@ -143,8 +147,8 @@ struct PanelSteps {
                 team_sync(x.team_ctr, x.team_expect, x.lane);
 #pragma unroll
                 for (int q = 0; q < RPT; ++q) {
-                    const int r = x.tid + q * PT;
-                    if (r < x.n && x.avail[q]) atomicMin(&x.red[0].pad, r);
+                    const int r = x.tr + q * TPR;
+                    if (x.h == 0 && r < x.n && x.avail[q]) atomicMin(&x.red[0].pad, r);
                 }
                 team_sync(x.team_ctr, x.team_expect, x.lane);
                 pphys = x.red[0].pad;
@@ -153,17 +157,19 @@ struct PanelSteps {
             // (2) publish the unscaled pivot row, 1/pivot and the pivot column
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int r = x.tid + q * PT;
+                const int r = x.tr + q * TPR;
                 if (r == pphys) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) x.rowbuf[s] = x.a[q][s];
-                    // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
-                    // overflow range for these matrices)
-                    const cplx pv = x.a[q][J];
-                    const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
-                    *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
+                    for (int s = 0; s < S; ++s) x.rowbuf[x.h * S + s] = x.a[q][s];
+                    if (x.h == hj) {
+                        // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
+                        // overflow range for these matrices)
+                        const cplx pv = x.a[q][sj];
+                        const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+                        *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
+                    }
                 }
-                x.colbuf[r] = x.a[q][J];
+                if (x.h == hj) x.colbuf[r] = x.a[q][sj];
             }
             if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
             team_sync(x.team_ctr, x.team_expect, x.lane);
@@ -172,11 +178,11 @@ struct PanelSteps {
             const cplx ip = *x.piv_ip;
             cplx nfm[RPT];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tid + q * PT], ip));   // -(f / pivot)
+            for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tr + q * TPR], ip));   // -(f / pivot)
             bool wave_has_piv = false;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int d = pphys - q * PT - x.wave_tr0;
+                const int d = pphys - q * TPR - x.wave_tr0;
                 wave_has_piv |= (d >= 0 && d < 64);
             }
             constexpr int HS = (S >= 8) ? 8 : S;
@@ -184,7 +190,7 @@ struct PanelSteps {
             for (int s0 = 0; s0 < S; s0 += HS) {
                 cplx rb[HS];
 #pragma unroll
-                for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[s0 + s];
+                for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[x.h * S + s0 + s];
                 if (!wave_has_piv) {
                     // select-free path: row <- row - (f/pivot) * pivot row
 #pragma unroll
@@ -195,7 +201,7 @@ struct PanelSteps {
                     // the wave holding the pivot row: that row becomes (pivot row) / pivot
 #pragma unroll
                     for (int q = 0; q < RPT; ++q) {
-                        const bool is_piv = (x.tid + q * PT) == pphys;
+                        const bool is_piv = (x.tr + q * TPR) == pphys;
                         const cplx coef = is_piv ? ip : nfm[q];
 #pragma unroll
                         for (int s = 0; s < HS; ++s) {
@@ -208,19 +214,20 @@ struct PanelSteps {
             // pivot-column entry: 1/pivot on the pivot row, -(f/pivot) elsewhere
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const bool is_piv = (x.tid + q * PT) == pphys;
-                x.a[q][J] = is_piv ? ip : nfm[q];
+                const bool is_piv = (x.tr + q * TPR) == pphys;
+                if (x.h == hj) x.a[q][sj] = is_piv ? ip : nfm[q];
                 x.avail[q] = x.avail[q] && !is_piv;
             }
-            // (4) pivot search for column J+1 on the freshly updated strips
+            // (4) pivot search for column J+1 on the freshly updated strips (its owner waves)
             if constexpr (J + 1 < NB) {
-                if (J + 1 < x.kw) {
+                constexpr int hn = (J + 1) / S, sn = (J + 1) % S;
+                if (x.h == hn && J + 1 < x.kw) {            // wave-uniform: a wave belongs to one column part
                     double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
                     for (int q = 0; q < RPT; ++q) {
-                        const int r = x.tid + q * PT;
+                        const int r = x.tr + q * TPR;
                         if (r < x.n && x.avail[q]) {
-                            const double v = cabs1(x.a[q][J + 1]);
+                            const double v = cabs1(x.a[q][sn]);
                             const bool take = (v > bv) | ((v == bv) & (r < bkey));
                             bv = take ? v : bv; bkey = take ? r : bkey;
                         }
@@ -231,19 +238,19 @@ struct PanelSteps {
                 }
             }
             team_sync(x.team_ctr, x.team_expect, x.lane);
-            if constexpr (J + 1 < NB) PanelSteps<NB, RPT, J + 1>::run(x);
+            if constexpr (J + 1 < NB) PanelSteps<NB, CPR, RPT, J + 1>::run(x);
         }
     }
 };
 
-template <int NB, int RPT>
+template <int NB, int CPR, int RPT>
 __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
     int dbg /* ablation switches, 0 in production: 2 = no MFMA, 4 = no tile loads, 16 = U-team idle,
                32 = no pivot steps */)
 {
-    using C = GjCfg<NB, RPT>;
-    constexpr int S = C::S;
+    using C = GjCfg<NB, CPR, RPT>;
+    constexpr int S = C::S, TPR = C::TPR;
     constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -257,9 +264,12 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     __shared__ cplx piv_ip;
     __shared__ int bad_sh;
     __shared__ int team_ctr;
+    __shared__ int next_item;        // work queue of the update items of the current step
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool pwave = wave < PW;
+    const int h = (tid % PT) / TPR;          // column part of the panel held by this thread (wave-uniform)
+    const int tr = (tid % PT) - h * TPR;     // row slot
     cplx* W = bufA + (size_t)blockIdx.x * mat_stride;            // the matrix, updated in place
     cplx* X = bufB + (size_t)blockIdx.x * mat_stride;            // Q snapshots, then the result
     int team_expect = 0;
@@ -283,42 +293,45 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
         bool avail[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int r = tid + q * PT;
+            const int r = tr + q * TPR;
             const bool row_ok = r < n;
             avail[q] = row_ok && (colof[r < rows16 ? r : 0] < 0);
-            const cplx* g = W + (size_t)(row_ok ? r : 0) * n + p0;
+            const cplx* g = W + (size_t)(row_ok ? r : 0) * n + p0 + h * S;
 #pragma unroll
             for (int s = 0; s < S; ++s)
-                a[q][s] = (row_ok && s < pw) ? g[s] : cmake(0.0, 0.0);
+                a[q][s] = (row_ok && h * S + s < pw) ? g[s] : cmake(0.0, 0.0);
         }
-        double bv = -1.0; int bkey = KEY_NONE;
+        if (h == 0) {                                       // waves owning column 0 of the panel
+            double bv = -1.0; int bkey = KEY_NONE;
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = tid + q * PT;
-            if (r < n && avail[q]) {
-                const double v = cabs1(a[q][0]);
-                const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                bv = take ? v : bv; bkey = take ? r : bkey;
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tr + q * TPR;
+                if (r < n && avail[q]) {
+                    const double v = cabs1(a[q][0]);
+                    const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                    bv = take ? v : bv; bkey = take ? r : bkey;
+                }
             }
+            wave_argmax(bv, bkey);
+            if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
         }
-        wave_argmax(bv, bkey);
-        if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
         team_sync(&team_ctr, team_expect, lane);
         if (!(dbg & 32)) {
-            PanelCtx<NB, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
-                                  &team_ctr, team_expect, n, p0, pw, tid, lane, wave, tid & ~63};
-            PanelSteps<NB, RPT, 0>::run(ctx);
+            PanelCtx<NB, CPR, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
+                                       &team_ctr, team_expect, n, p0, pw, tid, lane, wave, h, tr,
+                                       (tid & ~63) - h * TPR};
+            PanelSteps<NB, CPR, RPT, 0>::run(ctx);
         } else if (tid == 0) {
             for (int j = 0; j < pw; ++j) { pivrow[p0 + j] = p0 + j; colof[p0 + j] = p0 + j; }
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int r = tid + q * PT;
+            const int r = tr + q * TPR;
             if (r < n) {
-                cplx* g = W + (size_t)r * n + p0;
+                cplx* g = W + (size_t)r * n + p0 + h * S;
 #pragma unroll
                 for (int s = 0; s < S; ++s)
-                    if (s < pw) g[s] = a[q][s];
+                    if (h * S + s < pw) g[s] = a[q][s];
             }
         }
     };
@@ -405,37 +418,61 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                     }
                 }
             }
-            // ---------------- pivot rows -> Q snapshot X[k][:]
-            for (int k = wave; k < kw; k += GJB_WAVES) {
-                const cplx* srow = W + (size_t)pivrow[k0 + k] * n;
-                cplx* drow = X + (size_t)k * n;
-                for (int j = lane; j < n; j += 64) drow[j] = srow[j];
+            // ---------------- pivot rows -> Q snapshot X[k][:]  (a wave copies up to 4 rows at a time
+            // with all their loads in flight)
+            for (int kb = wave * 4; kb < kw; kb += GJB_WAVES * 4) {
+                for (int j0 = 0; j0 < n; j0 += 128) {
+                    cplx v[4][2];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int k = kb + rr;
+                        const cplx* srow = W + (size_t)pivrow[k0 + (k < kw ? k : 0)] * n;
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = j0 + jj * 64 + lane;
+                            v[rr][jj] = (k < kw && j < n) ? srow[j] : cmake(0.0, 0.0);
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int k = kb + rr;
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = j0 + jj * 64 + lane;
+                            if (k < kw && j < n) X[(size_t)k * n + j] = v[rr][jj];
+                        }
+                    }
+                }
             }
+            if (tid == 0) next_item = 0;
             __syncthreads();             // [A] Pt, Q snapshot visible; pivot rows of W are not read again
         }
-        if (pwave && has_next) {
-            // ---- P-team: apply step k to the columns of block column s+1, then factor it
-            if (has_cur) {
-                const int t_lo = n0 >> 4, t_hi = (n0 + nw + 15) >> 4;    // column tiles touching [n0, n0+nw)
-                const int nq = 4;                                        // row quarters
-                const int rq = (tiles + nq - 1) / nq;
-                for (int item = wave; item < (t_hi - t_lo) * nq; item += PW) {
-                    const int tj = t_lo + item / nq, part = item % nq;
+        if (has_cur && has_next) {
+            // ---- every wave: apply step s to the columns of block column s+1 first (look-ahead)
+            const int t_lo = n0 >> 4, t_hi = (n0 + nw + 15) >> 4;        // column tiles touching [n0, n0+nw)
+            const int nq = 6;                                            // row ranges per column tile
+            const int rq = (tiles + nq - 1) / nq;
+            for (int item = wave; item < (t_hi - t_lo) * nq; item += GJB_WAVES) {
+                const int tj = t_lo + item / nq, part = item % nq;
+                if (part * rq < tiles)
                     update_item(k0, kw, tj, part * rq, min(tiles, part * rq + rq), n0, n0 + nw, true);
-                }
-                team_sync(&team_ctr, team_expect, lane);
             }
-            factor_panel(n0, nw);
-        } else if (has_cur && !((dbg & 16) && has_next)) {
-            // ---- U-team (everybody on the last step): all other column tiles
-            const int nwav = has_next ? UW : GJB_WAVES;
-            const int w0 = has_next ? wave - PW : wave;
+            __syncthreads();             // [A2] block column s+1 is up to date
+        }
+        // ---- P-team: factor block column s+1; U-team: update the other columns.  The update items
+        // come from a shared queue, so the P-team joins in as soon as its panel is done.
+        if (pwave && has_next) factor_panel(n0, nw);
+        if (has_cur && !((dbg & 16) && has_next)) {
             const int rhalf = (tiles + 1) >> 1;
-            for (int item = w0; item < tiles * 2; item += nwav) {
+            while (true) {
+                int item = 0;
+                if (lane == 0) item = atomicAdd(&next_item, 1);
+                item = __builtin_amdgcn_readfirstlane(item);
+                if (item >= tiles * 2) break;
                 const int tj = item >> 1, part = item & 1;
                 const int c_lo = tj * 16, c_hi = min(n, c_lo + 16);
                 if (c_lo >= k0 && c_hi <= k0 + kw) continue;                         // inside block column s
-                if (has_next && c_lo >= n0 && c_hi <= n0 + nw) continue;             // done by the P-team
+                if (has_next && c_lo >= n0 && c_hi <= n0 + nw) continue;             // done in the look-ahead
                 update_item(k0, kw, tj, part ? rhalf : 0, part ? tiles : rhalf,
                             has_next ? n0 : 0, has_next ? n0 + nw : 0, false);
             }
@@ -466,10 +503,10 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     }
 }
 
-template <int NB, int RPT>
+template <int NB, int CPR, int RPT>
 size_t gj_smem(int n)
 {
-    using C = GjCfg<NB, RPT>;
+    using C = GjCfg<NB, CPR, RPT>;
     const size_t rows16 = (size_t)((n + 15) & ~15);
     return (size_t)NB * rows16 * sizeof(cplx) + NB * sizeof(cplx) + (size_t)C::ROWS * sizeof(cplx) +
            2 * rows16 * sizeof(int);
@@ -477,17 +514,17 @@ size_t gj_smem(int n)
 
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;      // static __shared__ of the kernel is < 1 KB
 
-template <int NB, int RPT>
+template <int NB, int CPR, int RPT>
 bool gj_fits(int n)
 {
-    return n <= GjCfg<NB, RPT>::ROWS && gj_smem<NB, RPT>(n) <= LDS_LIMIT;
+    return n <= GjCfg<NB, CPR, RPT>::ROWS && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
 }
 
-template <int NB, int RPT>
+template <int NB, int CPR, int RPT>
 void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
-    auto kern = gj_blocked_kernel<NB, RPT>;
-    const size_t smem = gj_smem<NB, RPT>(n);
+    auto kern = gj_blocked_kernel<NB, CPR, RPT>;
+    const size_t smem = gj_smem<NB, CPR, RPT>(n);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -503,9 +540,8 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
 int gj_pick(int n)
 {
     if (n < 32) return 0;                               // small matrices: the unblocked kernel
-    if (gj_fits<32, 1>(n)) return 1;                    // n <= 256, panel 32
-    if (gj_fits<16, 2>(n)) return 2;                    // n <= 512, panel 16
-    if (gj_fits<8, 4>(n)) return 3;                     // n <= ~960, panel 8
+    if (gj_fits<32, 2, 1>(n)) return 1;                 // n <= 256, panel 32, two threads per row
+    if (gj_fits<16, 1, 1>(n)) return 2;                 // n <= 512, panel 16
     return 0;
 }
 
@@ -518,9 +554,8 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0; }
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
     switch (gj_pick(n)) {
-    case 1: gj_launch<32, 1>(st, n, nb, A, B, stride, info); break;
-    case 2: gj_launch<16, 2>(st, n, nb, A, B, stride, info); break;
-    case 3: gj_launch<8, 4>(st, n, nb, A, B, stride, info); break;
+    case 1: gj_launch<32, 2, 1>(st, n, nb, A, B, stride, info); break;
+    case 2: gj_launch<16, 1, 1>(st, n, nb, A, B, stride, info); break;
     default: return false;
     }
     return true;
