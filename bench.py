@@ -60,25 +60,46 @@ def legendre_grid(M, lo=-3.0, hi=3.0):
 
 
 def cpu_baseline(F, S, inds, E, w, budget_s=12.0):
-    """Time the oracle's GrInt (plain numpy loop, solve(A, I)) on a bounded sample."""
+    """Time the oracle's GrInt (plain numpy loop, solve(A, I)) on a bounded sample.
+
+    The BLAS thread count that is fastest for this matrix size on this host is used
+    (all cores is NOT the fastest for N ~ 200: oversubscription), so the baseline is the
+    best the reference's CPU path can do here; `cores` reports that thread count."""
     import oracle
     g = oracle.ConstSigma(F, S, inds, -0.1j)
-    t0 = time.perf_counter()
-    oracle.GrInt(F, S, g, E[:8], w[:8])                      # warm-up + rate estimate
-    per = (time.perf_counter() - t0) / 8
-    n = int(max(16, min(len(E), budget_s / max(per, 1e-6))))
-    idx = np.linspace(0, len(E) - 1, n).astype(int)
-    t0 = time.perf_counter()
-    oracle.GrInt(F, S, g, E[idx], w[idx])
-    dt = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_limits
     except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": n / dt, "unit": "energy-points/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n} of {len(E)} energies of the same N_orb={F.shape[0]} workload, "
-                      f"numpy {np.__version__} solve(A,I) loop (oracle.GrInt), {dt:.2f} s"}
+        threadpool_limits = None
+    best_t, best_per = ncpu, None
+    cands = sorted({t for t in (1, 4, 8, 16, 32, 64, ncpu) if t <= ncpu}) if threadpool_limits else [ncpu]
+    for t in cands:
+        ctx = threadpool_limits(limits=t) if threadpool_limits else None
+        try:
+            oracle.GrInt(F, S, g, E[:2], w[:2])
+            t0 = time.perf_counter()
+            oracle.GrInt(F, S, g, E[:6], w[:6])
+            per = (time.perf_counter() - t0) / 6
+        finally:
+            if ctx is not None:
+                ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
+        if best_per is None or per < best_per:
+            best_t, best_per = t, per
+    n = int(max(16, min(len(E), budget_s / max(best_per, 1e-6))))
+    idx = np.linspace(0, len(E) - 1, n).astype(int)
+    ctx = threadpool_limits(limits=best_t) if threadpool_limits else None
+    try:
+        t0 = time.perf_counter()
+        oracle.GrInt(F, S, g, E[idx], w[idx])
+        dt = time.perf_counter() - t0
+    finally:
+        if ctx is not None:
+            ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
+    return {"value": n / dt, "unit": "energy-points/s", "cores": int(best_t), "kind": "port",
+            "sample": f"{n} of {len(E)} energies of the same N_orb={F.shape[0]} workload, numpy {np.__version__} "
+                      f"solve(A,I) loop (oracle.GrInt), best of BLAS threads {cands} = {best_t} "
+                      f"(host has {ncpu} logical CPUs), {dt:.2f} s"}
 
 
 def main():

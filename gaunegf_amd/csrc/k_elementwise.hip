@@ -131,22 +131,50 @@ void launch_gamma_dense(hipStream_t st, int n, int nb, const cplx* sig, size_t s
 }
 
 // -------------------------------------------------------------- accumulate
-// acc[i] += sum_b w[b] * X[b][i], b ascending inside one thread -> the summation
-// order over energies is fixed (bitwise reproducible from run to run).
-__global__ __launch_bounds__(EW_THREADS) void accumulate_kernel(
-    int n2, int nb, const cplx* __restrict__ w, const cplx* __restrict__ X, cplx* __restrict__ acc)
+// acc[i] += sum_b w[b] * X[b][i] in a FIXED order (bitwise reproducible from run to run):
+// the batch is cut into chunks of ACC_CHUNK energies; pass 1 reduces each chunk into
+// part[chunk][i] (b ascending inside the chunk, 4 independent loads in flight per thread),
+// pass 2 adds the chunk sums in ascending chunk order.  Enough workgroups to stream the
+// batch at HBM rate (a single pass over i alone launches only n^2/256 workgroups).
+static constexpr int ACC_CHUNK = 32;
+
+__global__ __launch_bounds__(EW_THREADS) void accumulate_partial_kernel(
+    int n2, int nb, const cplx* __restrict__ w, const cplx* __restrict__ X, cplx* __restrict__ part)
+{
+    const int i = blockIdx.x * EW_THREADS + threadIdx.x;
+    const int b0 = blockIdx.y * ACC_CHUNK, b1 = min(nb, b0 + ACC_CHUNK);
+    if (i >= n2) return;
+    cplx a = cmake(0.0, 0.0);
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        const cplx x0 = X[(size_t)(b + 0) * n2 + i], x1 = X[(size_t)(b + 1) * n2 + i];
+        const cplx x2 = X[(size_t)(b + 2) * n2 + i], x3 = X[(size_t)(b + 3) * n2 + i];
+        a = cfma(a, w[b + 0], x0); a = cfma(a, w[b + 1], x1);
+        a = cfma(a, w[b + 2], x2); a = cfma(a, w[b + 3], x3);
+    }
+    for (; b < b1; ++b) a = cfma(a, w[b], X[(size_t)b * n2 + i]);
+    part[(size_t)blockIdx.y * n2 + i] = a;
+}
+
+__global__ __launch_bounds__(EW_THREADS) void accumulate_final_kernel(
+    int n2, int nchunks, const cplx* __restrict__ part, cplx* __restrict__ acc)
 {
     const int i = blockIdx.x * EW_THREADS + threadIdx.x;
     if (i >= n2) return;
     cplx a = acc[i];
-    for (int b = 0; b < nb; ++b) a = cfma(a, w[b], X[(size_t)b * n2 + i]);
+    for (int c = 0; c < nchunks; ++c) a = cadd(a, part[(size_t)c * n2 + i]);
     acc[i] = a;
 }
 
-void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc)
+// `part` must hold ceil(nb / ACC_CHUNK) * n2 elements
+size_t accumulate_scratch_elems(int n2, int nb) { return (size_t)((nb + ACC_CHUNK - 1) / ACC_CHUNK) * n2; }
+
+void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc, cplx* part)
 {
     const int g = (n2 + EW_THREADS - 1) / EW_THREADS;
-    hipLaunchKernelGGL(accumulate_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nb, w, X, acc);
+    const int nchunks = (nb + ACC_CHUNK - 1) / ACC_CHUNK;
+    hipLaunchKernelGGL(accumulate_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n2, nb, w, X, part);
+    hipLaunchKernelGGL(accumulate_final_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nchunks, part, acc);
 }
 
 // ------------------------------------------------------------------ reductions

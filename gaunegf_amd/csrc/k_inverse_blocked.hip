@@ -545,18 +545,303 @@ int gj_pick(int n)
     return 0;
 }
 
+
+// ======================================================================================
+// Large matrices (n > 512): the same in-place, implicit-pivot Gauss-Jordan reduction,
+// blocked at TWO levels across kernels.  For each window of WIN = 64 columns:
+//   gj_window_kernel  (one workgroup per matrix): factors the n x 64 block column in
+//       sub-panels of NBI columns with the register-strip pivot steps above and applies
+//       every sub-panel transform to the 64 window columns only (MFMA, operands L2-hot);
+//       afterwards the window holds the block column P' of the combined transform and the
+//       64 pivot rows are snapshotted as Q (their other columns are still untouched).
+//   gj_bigupdate_kernel (a 64 x 64 output block per workgroup, all other columns):
+//       W[i][J] = (i pivot row of this window ? 0 : W[i][J]) + P'[i][:] * Q[:][J]
+//       an LDS-tiled complex GEMM on the FP64 matrix cores with K = 64: 16 flop per byte of
+//       matrix traffic, i.e. compute-bound for n >~ 500.
+// pivrow / colof live in global memory between launches.  gj_gather_kernel forms
+// G[i][j] = W[pivrow[i]][colof[j]].
+// ======================================================================================
+constexpr int WIN = 64;
+
+template <int NBI, int RPT>
+__global__ __launch_bounds__(PT) void gj_window_kernel(
+    int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride,
+    int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw)
+{
+    using C = GjCfg<NBI, 1, RPT>;
+    constexpr int S = NBI;
+    constexpr int KS = (NBI + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx* rowbuf = reinterpret_cast<cplx*>(smem_raw);            // [NBI]
+    cplx* colbuf = rowbuf + NBI;                                 // [ROWS]
+    cplx* qwin = colbuf + C::ROWS;                               // [NBI][WIN] pivot rows, window columns
+    __shared__ RedSlot red[2][PW];
+    __shared__ cplx piv_ip;
+    __shared__ int bad_sh;
+    __shared__ int team_ctr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cplx* W = bufA + (size_t)blockIdx.x * mat_stride;
+    cplx* X = bufB + (size_t)blockIdx.x * mat_stride;
+    int* pivrow = piv_all + (size_t)blockIdx.x * 2 * n;
+    int* colof = pivrow + n;
+    int team_expect = 0;
+    if (tid == 0) { bad_sh = 0; team_ctr = 0; }
+    __syncthreads();
+
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tiles = (n + 15) >> 4;
+    const int wt0 = c0 >> 4, wt1 = (c0 + cw + 15) >> 4;          // column tiles of the window
+
+    for (int k0 = c0; k0 < c0 + cw; k0 += NBI) {
+        const int kw = min(NBI, c0 + cw - k0);
+        __syncthreads();                 // previous window update (global stores) complete
+        // ---- strips of the sub-panel, pivot steps (all 8 waves form the panel team)
+        cplx a[RPT][S];
+        bool avail[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + q * PT;
+            const bool row_ok = r < n;
+            avail[q] = row_ok && (colof[row_ok ? r : 0] < 0);
+            const cplx* g = W + (size_t)(row_ok ? r : 0) * n + k0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) a[q][s] = (row_ok && s < kw) ? g[s] : cmake(0.0, 0.0);
+        }
+        {
+            double bv = -1.0; int bkey = KEY_NONE;
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int r = tid + q * PT;
+                if (r < n && avail[q]) {
+                    const double v = cabs1(a[q][0]);
+                    const bool take = (v > bv) | ((v == bv) & (r < bkey));
+                    bv = take ? v : bv; bkey = take ? r : bkey;
+                }
+            }
+            wave_argmax(bv, bkey);
+            if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
+        }
+        team_sync(&team_ctr, team_expect, lane);
+        {
+            PanelCtx<NBI, 1, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
+                                      &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, tid & ~63};
+            PanelSteps<NBI, 1, RPT, 0>::run(ctx);
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = tid + q * PT;
+            if (r < n) {
+                cplx* g = W + (size_t)r * n + k0;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    if (s < kw) g[s] = a[q][s];
+            }
+        }
+        __syncthreads();                 // sub-panel columns and pivrow/colof (global) visible
+        // ---- pivot rows of this sub-panel, window columns -> LDS
+        for (int t = tid; t < NBI * WIN; t += PT) {
+            const int k = t / WIN, j = t - k * WIN;
+            qwin[t] = (k < kw && c0 + j < n && j < cw) ? W[(size_t)pivrow[k0 + k] * n + c0 + j] : cmake(0.0, 0.0);
+        }
+        __syncthreads();
+        // ---- apply the sub-panel transform to the other window columns (in place)
+        for (int item = wave; item < tiles * (wt1 - wt0); item += PW) {
+            const int ti = item / (wt1 - wt0), tj = wt0 + item % (wt1 - wt0);
+            const int col = tj * 16 + fi;
+            const bool col_ok = col < n && col >= c0 && col < c0 + cw;
+            const bool col_store = col_ok && !(col >= k0 && col < k0 + kw);
+            d4 accr = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fk + 4 * r;
+                if (i < n && col_ok) {
+                    const int cf = colof[i];
+                    if (!(cf >= k0 && cf < k0 + kw)) { const cplx v = W[(size_t)i * n + col]; accr[r] = v.x; acci[r] = v.y; }
+                }
+            }
+            const int prow = ti * 16 + fi;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 4 + fk;
+                cplx pa = cmake(0.0, 0.0), qb = cmake(0.0, 0.0);
+                if (prow < n && k < kw) pa = W[(size_t)prow * n + k0 + k];
+                if (k < kw && col_ok) qb = qwin[k * WIN + (col - c0)];
+                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qb.x, accr, 0, 0, 0);
+                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qb.y, accr, 0, 0, 0);
+                acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qb.y, acci, 0, 0, 0);
+                acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qb.x, acci, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fk + 4 * r;
+                if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- Q snapshot for the big update: the cw pivot rows of this window, all columns
+    for (int k = wave; k < cw; k += PW) {
+        const cplx* srow = W + (size_t)pivrow[c0 + k] * n;
+        cplx* drow = X + (size_t)k * n;
+        for (int j = lane; j < n; j += 64) drow[j] = srow[j];
+    }
+    if (tid == 0 && bad_sh != 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad_sh;
+}
+
+// W[i][J] = (row i pivot of the window ? 0 : W[i][J]) + P'[i][0:cw) * Q[0:cw)[J]  for the column
+// blocks outside the window.  Workgroup = 256 threads = 4 waves, 64 x 64 output block, wave tile
+// 32 x 32 (2 x 2 MFMA tiles), K tile 16 through LDS (same tiling as zgemm_mfma_kernel).
+__global__ __launch_bounds__(256) void gj_bigupdate_kernel(
+    int n, cplx* __restrict__ bufA, const cplx* __restrict__ bufB, size_t mat_stride,
+    const int* __restrict__ piv_all, int c0, int cw)
+{
+    constexpr int BM = 64, BN = 64, BK = 16, AP = BK + 1, BP = BN + 1;
+    __shared__ cplx As[BM * AP];
+    __shared__ cplx Bs[BK * BP];
+    const int col0 = blockIdx.x * BN, row0 = blockIdx.y * BM;
+    if (col0 >= c0 && col0 < c0 + cw) return;                    // window columns: already final (uniform)
+    cplx* W = bufA + (size_t)blockIdx.z * mat_stride;
+    const cplx* Q = bufB + (size_t)blockIdx.z * mat_stride;
+    const int* colof = piv_all + (size_t)blockIdx.z * 2 * n + n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int fi = lane & 15, fk = lane >> 4;
+    d4 accr[2][2], acci[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + c * 16 + fi;
+                double vx = 0.0, vy = 0.0;
+                if (gi < n && gj < n) {
+                    const int cf = colof[gi];
+                    if (!(cf >= c0 && cf < c0 + cw)) { const cplx v = W[(size_t)gi * n + gj]; vx = v.x; vy = v.y; }
+                }
+                accr[a][c][r] = vx; acci[a][c][r] = vy;
+            }
+    const int lr = tid >> 2, lc = (tid & 3) * 4;                 // A tile staging: row lr, k lc..lc+3
+    const int br = tid >> 4, bc = (tid & 15) * 4;                // B tile staging: k br, cols bc..bc+3
+    for (int k0 = 0; k0 < cw; k0 += BK) {
+        {
+            const int gi = row0 + lr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gk = k0 + lc + e;
+                As[lr * AP + lc + e] = (gi < n && gk < cw) ? W[(size_t)gi * n + c0 + gk] : cmake(0.0, 0.0);
+            }
+            const int gk = k0 + br;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gj = col0 + bc + e;
+                Bs[br * BP + bc + e] = (gk < cw && gj < n) ? Q[(size_t)gk * n + gj] : cmake(0.0, 0.0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 4) {
+            cplx af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = As[(wr + a * 16 + fi) * AP + ks + fk];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bf[c] = Bs[(ks + fk) * BP + wc + c * 16 + fi];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].x, accr[a][c], 0, 0, 0);
+                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf[c].y, accr[a][c], 0, 0, 0);
+                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].y, acci[a][c], 0, 0, 0);
+                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf[c].x, acci[a][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + c * 16 + fi;
+                if (gi < n && gj < n) W[(size_t)gi * n + gj] = cmake(accr[a][c][r], acci[a][c][r]);
+            }
+}
+
+__global__ __launch_bounds__(256) void gj_gather_kernel(int n, const cplx* __restrict__ bufA,
+                                                         cplx* __restrict__ bufB, size_t mat_stride,
+                                                         const int* __restrict__ piv_all)
+{
+    const cplx* W = bufA + (size_t)blockIdx.y * mat_stride;
+    cplx* X = bufB + (size_t)blockIdx.y * mat_stride;
+    const int* pivrow = piv_all + (size_t)blockIdx.y * 2 * n;
+    const int* colof = pivrow + n;
+    const int i = blockIdx.x;
+    const cplx* srow = W + (size_t)pivrow[i] * n;
+    for (int j = threadIdx.x; j < n; j += 256) X[(size_t)i * n + j] = srow[colof[j]];
+}
+
+__global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __restrict__ info)
+{
+    int* p = piv_all + (size_t)blockIdx.x * 2 * n;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { p[t] = 0; p[n + t] = -1; }
+    if (threadIdx.x == 0) info[blockIdx.x] = 0;
+}
+
+template <int NBI, int RPT>
+void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
+{
+    using C = GjCfg<NBI, 1, RPT>;
+    const size_t smem = (size_t)(NBI + C::ROWS + NBI * WIN) * sizeof(cplx);
+    auto kern = gj_window_kernel<NBI, RPT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(100 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gj_state_init_kernel, dim3(nb), dim3(256), 0, st, n, piv, info);
+    const int nblk = (n + 63) / 64;
+    for (int c0 = 0; c0 < n; c0 += WIN) {
+        const int cw = min(WIN, n - c0);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, B, stride, piv, info, c0, cw);
+        hipLaunchKernelGGL(gj_bigupdate_kernel, dim3(nblk, nblk, nb), dim3(256), 0, st, n, A, B, stride,
+                           (const int*)piv, c0, cw);
+    }
+    hipLaunchKernelGGL(gj_gather_kernel, dim3(n, nb), dim3(256), 0, st, n, (const cplx*)A, B, stride,
+                       (const int*)piv);
+}
+
+int gj_large_pick(int n)
+{
+    if (n <= 512 || n < 64) return 0;
+    if (n <= PT * 2) return 1;           // <= 1024: sub-panel 8, 2 rows per thread
+    if (n <= PT * 4) return 2;           // <= 2048: sub-panel 8, 4 rows per thread
+    if (n <= PT * 8) return 3;           // <= 4096: sub-panel 4, 8 rows per thread
+    return 0;
+}
+
 }  // namespace
 
-bool inverse_blocked_supported(int n) { return gj_pick(n) != 0; }
+bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(n) != 0; }
 
 // In-place reduction of A with B as scratch; the inverses are gathered into B.
+// piv: [nb][2][n] ints of pivot bookkeeping (used by the large-matrix path).
 // Returns true: the result is in B.
-bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
 {
     switch (gj_pick(n)) {
-    case 1: gj_launch<32, 2, 1>(st, n, nb, A, B, stride, info); break;
-    case 2: gj_launch<16, 1, 1>(st, n, nb, A, B, stride, info); break;
+    case 1: gj_launch<32, 2, 1>(st, n, nb, A, B, stride, info); return true;
+    case 2: gj_launch<16, 1, 1>(st, n, nb, A, B, stride, info); return true;
+    default: break;
+    }
+    switch (gj_large_pick(n)) {
+    case 1: gj_large_launch<8, 2>(st, n, nb, A, B, stride, piv, info); return true;
+    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info); return true;
+    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info); return true;
     default: return false;
     }
-    return true;
 }

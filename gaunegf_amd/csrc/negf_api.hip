@@ -122,7 +122,7 @@ int ensure_workspace(negf_ctx* c, int m, int blk_stride, int min_batch = 1)
         if ((rc = dev_alloc(&c->d_A, n2 * want))) return rc;
         if ((rc = dev_alloc(&c->d_T1, n2 * want))) return rc;
         if ((rc = dev_alloc(&c->d_T2, n2 * want))) return rc;
-        if ((rc = dev_alloc(&c->d_ipiv, (size_t)c->n * want))) return rc;
+        if ((rc = dev_alloc(&c->d_ipiv, (size_t)2 * c->n * want))) return rc;
         if ((rc = dev_alloc(&c->d_site, (size_t)c->n * want))) return rc;
         c->batch = want;
     }
@@ -185,7 +185,7 @@ void run_inverse(negf_ctx* c, int nb, int* info)
     if (algo == 0) algo = inverse_blocked_supported(c->n) ? 2 : 1;
     if (algo == 2 && !inverse_blocked_supported(c->n)) algo = 1;
     bool in_b = false;
-    if (algo == 2) in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, info);
+    if (algo == 2) in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info);
     else launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info);
     c->G = in_b ? c->d_T1 : c->d_A;
     c->W1 = in_b ? c->d_A : c->d_T1;
@@ -633,7 +633,7 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
         ProfScope ps(c, "accumulate");
-        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out);
+        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out, c->W2);
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
@@ -672,7 +672,7 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
             launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, 1, c->W1, n, n2);
         }
         ProfScope ps(c, "accumulate");
-        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out);
+        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());

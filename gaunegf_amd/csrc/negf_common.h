@@ -125,7 +125,7 @@ struct negf_ctx {
     int blk_cap = 0;
     cplx* d_scratch = nullptr;     // per-workgroup scratch of the Sigma kernels
     size_t scratch_cap = 0;
-    int* d_ipiv = nullptr;         // [batch][n]
+    int* d_ipiv = nullptr;         // [batch][2][n] pivot bookkeeping of the large-matrix inverse
     int* d_info = nullptr;         // [m_cap]
     int* d_iters = nullptr;        // [m_cap][contacts]
     int* d_conv = nullptr;
@@ -171,11 +171,13 @@ void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S
 void launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
 // out-of-place ping-pong between A and B (both [nb][stride]); returns true when the
 // inverses end up in B, false when in A
-bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info);
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info);
 bool inverse_blocked_supported(int n);
 
-// acc += sum_b w[b] * X[b]   (fixed order b = 0..nb-1, deterministic)
-void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc);
+// acc += sum_b w[b] * X[b]   (fixed summation order, deterministic); `part` is scratch of
+// accumulate_scratch_elems(n2, nb) elements (<= nb * n2 / 32)
+void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc, cplx* part);
+size_t accumulate_scratch_elems(int n2, int nb);
 
 // C[b] (M x N) = A[b] (M x K) * op(B[b]);  a batch stride of 0 broadcasts one matrix.
 // opB: 0 -> B is K x N (ldb >= N); 1 -> op(B) = B^H with B stored N x K (ldb >= K).

@@ -45,13 +45,16 @@ def test_library_is_loaded_in_process():
     assert "libnegf_hip.so" in maps
 
 
-@pytest.mark.parametrize("algo", [1, 2])
-@pytest.mark.parametrize("N", [1, 3, 17, 32, 40, 64, 100, 200])
+@pytest.mark.parametrize("N,algo", [(n, a) for n in (1, 3, 17, 32, 40, 64, 100, 200, 256) for a in (1, 2)] +
+                         [(n, 2) for n in (257, 300, 500, 512, 513, 600, 1030)])
 def test_G_of_E_per_energy(engine, N, algo):
-    """G(E) = solve(E S - F - Sigma, I) for every energy, both inverse kernels."""
+    """G(E) = solve(E S - F - Sigma, I) for every energy: unblocked kernel (algo 1), blocked
+    MFMA kernels (algo 2: panel 32 up to n=256, panel 16 up to 512, two-level above)."""
     from gaunegf_amd.integrate import GrBatch
     F, S, g_dev, g_ref = _const_provider(N, 100 + N)
     E = np.concatenate([np.linspace(-3, 3, 9), np.array([0.3 + 0.5j, -1.2 + 2j, 0.05 + 1e-3j])])
+    if N > 256:
+        E = E[[0, 4, 10]]
     engine.set_inverse_algo(algo)
     try:
         G = GrBatch(F, S, g_dev, E)
