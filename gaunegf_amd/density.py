@@ -286,3 +286,360 @@ def _compute_dos_at_energy(E, F, S, sigma_total):
         return float(eng.dos(h, [E], per_site=False)[0])
     finally:
         eng.sigma_free(h)
+
+
+# --------------------------------------------------------------------------- #
+# Integration limits and Fermi-level searches (gauNEGF/density.py:821-1515).
+# Pure callers of the grid integrals above: every density evaluation inside the
+# loops below is one GPU integral; F and S stay resident on the device between
+# calls (Engine.set_system skips identical uploads), only mu changes.
+# --------------------------------------------------------------------------- #
+from .config import FERMI_CALCULATION_TOL, FERMI_SEARCH_CYCLES, ENERGY_MIN   # noqa: E402
+
+FERMI_DEBUG = False
+
+
+def _orbital_energies(F, S, hermitian=False):
+    """Sorted real parts of eig(inv(S) F) (density.py:822, 994-996, 1048)."""
+    M = np.linalg.solve(np.asarray(S), np.asarray(F))
+    vals = np.linalg.eigvalsh(M) if hermitian else np.linalg.eigvals(M)
+    return np.sort(np.real(vals))
+
+
+def calcEmin(F, S, g, tol=FERMI_CALCULATION_TOL, maxN=MAX_CYCLES):
+    """Lower contour bound: walk down in 1 eV steps from (lowest orbital - 5 eV) until the
+    DOS falls below tol (density.py:821-836)."""
+    Emin = min(_orbital_energies(F, S)) - 5
+    counter = 0
+    dP = _compute_dos_at_energy(Emin, F, S, g.sigmaTot(Emin))
+    while dP > tol and counter < maxN:
+        Emin -= 1
+        dP = _compute_dos_at_energy(Emin, F, S, g.sigmaTot(Emin))
+        counter += 1
+    if counter == maxN:
+        print(f'Warning: Emin still not within tolerance (final value = {dP}) after {maxN} energy samples')
+    print(f'Calculated Emin: {Emin} eV, DOS = {dP:.2E}')
+    return Emin
+
+
+def _double_until_converged(evaluate, start, tol, maxN, label):
+    """Shared doubling loop of integralFit / integralFitNEGF: N <- 2N until the diagonal of
+    the density stops changing by more than tol; returns the last N that was needed."""
+    N = start
+    dP = np.inf
+    rho = None
+    while dP > tol and N < maxN:
+        N *= 2
+        rho_ = np.real(evaluate(N))
+        dP = max(abs(np.diag(rho_ - rho))) if rho is not None else max(abs(np.diag(rho_)))
+        print(f"MaxDP = {dP:.2E}")
+        rho = rho_
+    if dP < tol:
+        N /= 2
+    elif N >= maxN and dP > tol:
+        print(f'Warning: {label} still not within tolerance (final value = {dP})')
+    print(f'Final {label}: {N}')
+    return N
+
+
+def integralFit(F, S, g, mu, Eminf=ENERGY_MIN, tol=FERMI_CALCULATION_TOL, T=TEMPERATURE, maxN=MAX_CYCLES):
+    """(Emin, N1, N2): contour lower bound, contour points, real-axis points (density.py:838-914)."""
+    Emin = calcEmin(F, S, g, tol, maxN)
+    Ncomplex = _double_until_converged(
+        lambda N: densityComplexN(F, S, g, Emin, mu, N, T=T, showText=False), 4, tol, maxN, 'Ncomplex')
+    Nreal = _double_until_converged(
+        lambda N: densityRealN(F, S, g, Eminf, Emin, N, T=0, showText=False), 8, tol, maxN, 'Nreal')
+    return Emin, Ncomplex, Nreal
+
+
+def integralFitNEGF(F, S, g, fermi, qV, Eminf=ENERGY_MIN, tol=FERMI_CALCULATION_TOL, T=TEMPERATURE,
+                    maxGrid=MAX_GRID_POINTS):
+    """Grid size of the bias-window integral (density.py:916-966)."""
+    def both(N):
+        rho = np.real(densityGridN(F, S, g, fermi, fermi + (qV / 2), ind=0, N=N, T=T, showText=False))
+        return rho + np.real(densityGridN(F, S, g, fermi, fermi - (qV / 2), ind=-1, N=N, T=T, showText=False))
+    return _double_until_converged(both, 8, tol, maxGrid, 'Nnegf')
+
+
+def _count(P, S, nOrbs=0):
+    PS = P @ S
+    return np.trace(PS) if nOrbs == 0 else np.trace(PS[-nOrbs:, -nOrbs:])
+
+
+def calcFermi(g, ne, Emin, Emax, fermiGuess=0, N1=100, N2=50, Eminf=ENERGY_MIN, T=TEMPERATURE,
+              tol=FERMI_CALCULATION_TOL, maxcycles=MAX_CYCLES, nOrbs=0):
+    """Bisection on the electron count of a contact (density.py:1054-1143).
+    Returns (fermi, Emin, N1, N2)."""
+    dos_eminf = _compute_dos_at_energy(Eminf, g.F, g.S, g.sigmaTot(Eminf))
+    print(f'Eminf DOS = {dos_eminf}')
+    fermi = fermiGuess
+
+    def low(temp):
+        if N2 is None:
+            return densityReal(g.F, g.S, g, Eminf, Emin, tol, temp)
+        return densityRealN(g.F, g.S, g, Eminf, Emin, int(N2), temp, showText=False)
+
+    def upper(E):
+        if N1 is None:
+            return densityComplex(g.F, g.S, g, Emin, E, tol, T)
+        return densityComplexN(g.F, g.S, g, Emin, E, int(N1), T, showText=False, method='legendre')
+
+    nELow = _count(low(T), g.S, nOrbs)
+    print(f'Electrons below lowest onsite energy: {nELow}')
+    if nELow >= ne:
+        raise Exception('Calculated Fermi energy is below lowest orbital energy!')
+    Ncurr = -1
+    counter = 0
+    lBound, uBound = Emin, Emax
+    print('Calculating Fermi energy using bisection:')
+    while abs(ne - Ncurr) > tol and uBound - lBound > tol / 10 and counter < maxcycles:
+        g.setF(g.F, fermi, fermi)
+        p_ = np.real(low(0) + upper(fermi))
+        Ncurr = _count(p_, g.S, nOrbs)
+        dN = ne - Ncurr
+        if dN > 0 and fermi > lBound:
+            lBound = fermi
+        elif dN < 0 and fermi < uBound:
+            uBound = fermi
+        if abs(ne - Ncurr) > tol:
+            fermi = (uBound + lBound) / 2
+        print("DN:", dN, "Fermi:", fermi, "Bounds:", lBound, uBound)
+        counter += 1
+    if abs(ne - Ncurr) > tol and counter > maxcycles:
+        print(f'Warning: Fermi energy still not within tolerance! Ef = {fermi:.2f} eV, N = {Ncurr:.2f})')
+    print(f'Finished after {counter} iterations, Ef = {fermi:.2f}')
+    return fermi, Emin, N1, N2
+
+
+def getFermiContact(g, ne, tol=FERMI_CALCULATION_TOL, Eminf=ENERGY_MIN, maxcycles=MAX_CYCLES, T=TEMPERATURE,
+                    nOrbs=0):
+    """Fermi level of a contact (Bethe cluster or chain) from its electron count
+    (density.py:969-1003)."""
+    orbs = _orbital_energies(g.F, g.S)
+    fermi = (orbs[int(ne) - 1] + orbs[int(ne)]) / 2
+    Emin, N1, N2 = integralFit(g.F, g.S, g, fermi, Eminf, tol, T, maxN=maxcycles)
+    return calcFermi(g, ne, Emin, max(orbs), fermi, N1, N2, Eminf, T, tol, maxcycles, nOrbs)[0]
+
+
+def getFermi1DContact(gSys, ne, ind=0, tol=FERMI_CALCULATION_TOL, Eminf=ENERGY_MIN, T=TEMPERATURE,
+                      maxcycles=MAX_CYCLES):
+    """Fermi level of a 1-D chain lead: build the periodic lead from contact ``ind`` of gSys and
+    search its Fermi level (density.py:1005-1052).  Returns (fermi, Emin, N1, N2)."""
+    from .surfG1D import surfG
+    F = np.asarray(gSys.aList[ind]); S = np.asarray(gSys.aSList[ind])
+    tau = np.asarray(gSys.bList[ind]); stau = np.asarray(gSys.bSList[ind])
+    inds = np.arange(len(F))
+    g = surfG(F, S, [inds], [tau], [stau], eta=1e-6)
+    Forbs = np.block([[F, tau], [tau.conj().T, F]])
+    Sorbs = np.block([[S, stau], [stau.T, S]])
+    gorbs = surfG(Forbs, Sorbs, [inds], [tau], [stau], eta=1e-6)
+    orbs = _orbital_energies(Forbs, Sorbs, hermitian=False)
+    fermi = (orbs[2 * int(ne) - 1] + orbs[2 * int(ne)]) / 2
+    Emin, N1, N2 = integralFit(Forbs, Sorbs, gorbs, fermi, Eminf, tol, T, maxN=maxcycles)
+    return calcFermi(g, ne, Emin, max(orbs), fermi, N1, N2, Eminf, T, tol, maxcycles)
+
+
+def _mu_density(g, Emin, N, tol, T):
+    """P(mu) evaluator shared by the searches below (density.py:1150-1153 and alike)."""
+    if N is None:
+        return lambda E: densityComplex(g.F, g.S, g, Emin, E, tol, T)
+    return lambda E: densityComplexN(g.F, g.S, g, Emin, E, int(N), T, showText=False)
+
+
+def calcFermiBisect(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI_CALCULATION_TOL,
+                    maxcycles=FERMI_SEARCH_CYCLES, T=TEMPERATURE, uBound=None, lBound=None):
+    """Bracket with DOS-sized steps, then bisect (density.py:1145-1207).  Returns (Ef, dE, P).
+    (The reference passes (S, F) swapped to its DOS kernel at :1176; the intended (F, S) is used.)"""
+    assert ne < len(g.F), "Number of electrons cannot exceed number of basis functions!"
+    pMu = _mu_density(g, Emin, N, tol, T)
+    E = Ef + 0.0
+    dE = tol
+    counter = 0
+    g.setF(g.F, E, E)
+    P = pMu(E)
+    Ncurr = np.trace(P @ g.S).real
+    while None in [uBound, lBound] and counter < maxcycles:
+        if Ncurr > ne:
+            uBound = E + 0.0
+            Ef = uBound
+            E -= dE
+        if Ncurr < ne:
+            lBound = E + 0.0
+            Ef = lBound
+            E += dE
+        dos = _compute_dos_at_energy(E, g.F, g.S, g.sigmaTot(E))
+        dE = max(2 * abs(Ncurr - ne) / dos, dE)
+        counter += 1
+        g.setF(g.F, E, E)
+        P = pMu(E)
+        Ncurr = np.trace(P @ g.S).real
+    while abs(ne - Ncurr) > conv and counter < maxcycles and uBound != lBound:
+        dN = ne - Ncurr
+        if dN > 0 and Ef > lBound:
+            lBound = Ef + 0.0
+        elif dN < 0 and Ef < uBound:
+            uBound = Ef + 0.0
+        Ef = (uBound + lBound) / 2
+        dE = uBound - lBound
+        counter += 1
+        if abs(dN) > conv:
+            g.setF(g.F, Ef, Ef)
+            P = pMu(Ef)
+            Ncurr = np.trace(P @ g.S)
+    if counter == maxcycles:
+        print(f'Warning: Max cycles reached, convergence = {abs(Ncurr-ne):.2E}')
+    elif uBound == lBound:
+        print(f'Warning: Bisection failed, convergence = {abs(Ncurr-ne):.2E}')
+    return Ef, dE, P
+
+
+def calcFermiSecant(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI_CALCULATION_TOL,
+                    maxcycles=FERMI_SEARCH_CYCLES, T=TEMPERATURE):
+    """Secant iteration on N(mu) - ne (density.py:1209-1247).  Returns (Ef, dE, P, |dN|)."""
+    assert ne < len(g.F), "Number of electrons cannot exceed number of basis functions!"
+    pMu = _mu_density(g, Emin, N, tol, T)
+    g.setF(g.F, Ef, Ef)
+    P = pMu(Ef)
+    nCurr = np.trace(P @ g.S).real
+    dE = conv
+    counter = 0
+    while abs(nCurr - ne) > conv and counter < maxcycles:
+        Ef += dE
+        g.setF(g.F, Ef, Ef)
+        P = pMu(Ef)
+        nNext = np.trace(P @ g.S).real
+        if abs(nNext - nCurr) < 1e-10:
+            print('Warning: change in ne low, reducing step size')
+            dE *= 0.1
+            counter += 1
+            continue
+        dE = dE * ((ne - nCurr) / (nNext - nCurr)) - dE
+        nCurr = nNext + 0.0
+        counter += 1
+    Ef += dE
+    if counter == maxcycles:
+        print(f'Warning: Max cycles reached, convergence = {abs(nCurr-ne):.2E}')
+    return Ef, dE, P, abs(nCurr - ne)
+
+
+def _track_bounds(n, E, uBound, lBound):
+    if n > 0:
+        uBound = min(uBound, E) if uBound is not None else E
+    elif n < 0:
+        lBound = max(lBound, E) if lBound is not None else E
+    return uBound, lBound
+
+
+def calcFermiMuller(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI_CALCULATION_TOL,
+                    maxcycles=FERMI_SEARCH_CYCLES, T=TEMPERATURE):
+    """Muller's method from three points Ef, Ef -+ conv (density.py:1249-1330).
+    Returns (E, dE, P, |dN|, uBound, lBound)."""
+    assert ne < len(g.F), "Number of electrons cannot exceed number of basis functions!"
+    pMu = _mu_density(g, Emin, N, tol, T)
+    E2, E1, E0 = Ef, Ef - conv, Ef + conv
+    uBound = lBound = None
+    nList = []
+    P = None
+    for E in [E2, E1, E0]:
+        g.setF(g.F, E, E)
+        P = pMu(E)
+        n = np.trace(P @ g.S).real - ne
+        uBound, lBound = _track_bounds(n, E, uBound, lBound)
+        if abs(n) < conv:
+            return E, 0, P, abs(n), uBound, lBound
+        nList.append(n)
+    n2, n1, n0 = nList
+    counter = 3
+    dE = 0.0
+    while counter < maxcycles:
+        h0, h1 = E0 - E2, E1 - E2
+        c = n2
+        e0, e1 = n0 - c, n1 - c
+        det = h0 * h1 * (h0 - h1)
+        a = (e0 * h1 - h0 * e1) / det
+        b = (h0 * h0 * e1 - h1 * h1 * e0) / det
+        disc = np.sqrt(b * b - 4 * a * c) if b * b > 4 * a * c else 0
+        if b < 0:
+            disc = -disc
+        dE = -2 * c / (b + disc)
+        Enext = E2 + dE
+        if abs(Enext - E1) < abs(Enext - E0):
+            E0, E1 = E1, E0
+            n0, n1 = n1, n0
+        if abs(Enext - E2) < abs(Enext - E1):
+            E1, n1 = E2, n2
+        E2 = Enext
+        g.setF(g.F, E2, E2)
+        P = pMu(E2)
+        n2 = np.trace(P @ g.S).real - ne
+        uBound, lBound = _track_bounds(n2, E2, uBound, lBound)
+        if abs(n2) < conv:
+            break
+        counter += 1
+    if counter == maxcycles:
+        print(f'Warning: Max cycles reached, convergence = {abs(n2):.2E}')
+    return E2, dE, P, abs(n2), uBound, lBound
+
+
+def calcFermiPolyFit(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI_CALCULATION_TOL,
+                     maxcycles=FERMI_SEARCH_CYCLES, T=TEMPERATURE, order=3):
+    """Accumulate (E, N-ne) points, fit a robust (Huber) polynomial through a PCHIP-smoothed
+    version of them and step to its root nearest the last point, enforcing monotonicity
+    (density.py:1332-1515).  Returns (E, dE, P, |dN|, uBound, lBound)."""
+    from scipy.optimize import least_squares
+    from scipy.interpolate import PchipInterpolator
+    assert ne < len(g.F), "Number of electrons cannot exceed number of basis functions!"
+    pMu = _mu_density(g, Emin, N, tol, T)
+
+    def evaluate(E):
+        g.setF(g.F, E, E)
+        P = pMu(E)
+        return P, np.trace(P @ g.S).real - ne
+
+    E_pts, n_pts = [], []
+    uBound = lBound = None
+    E = Ef
+    P, n = evaluate(E)
+    if abs(n) < conv:
+        return E, 0, P, abs(n), uBound, lBound
+    E_pts.append(E); n_pts.append(n)
+    step = conv * 10
+    n_first = n
+    counter = 1
+    while counter < maxcycles:              # a second point with a resolvable change of N
+        E = Ef + step
+        P, n = evaluate(E)
+        uBound, lBound = _track_bounds(n, E, uBound, lBound)
+        if abs(n) < conv:
+            return E, step, P, abs(n), uBound, lBound
+        if n - n_first > 0:
+            break
+        step *= 10
+        counter += 1
+    E_pts.append(E); n_pts.append(n)
+    dE = step
+    while counter < maxcycles:
+        poly_order = min(len(n_pts) - 1, order)
+        Esort, nsort = list(zip(*sorted(zip(E_pts, n_pts))))
+        n_smooth = PchipInterpolator(Esort, nsort)(E_pts)
+        p0 = np.polyfit(E_pts, n_pts, poly_order)
+        fit = least_squares(lambda cf: np.polyval(cf, E_pts) - n_smooth, p0, loss='huber',
+                            f_scale=ADAPTIVE_INTEGRATION_TOL)
+        roots = np.roots(fit.x)
+        E_next = roots[np.argmin(np.abs(roots - E_pts[-1]))].real
+        if (n_pts[-1] > 0 and E_next > E_pts[-1]) or (n_pts[-1] < 0 and E_next < E_pts[-1]):
+            # the fit violated "higher E -> higher N": drop the last point, step the right way
+            E_next = E_pts[-1] - np.sign(n_pts[-1]) * abs(dE) * 10
+            E_pts.pop(); n_pts.pop()
+            counter -= 1
+        E = E_next
+        P, n = evaluate(E)
+        uBound, lBound = _track_bounds(n, E, uBound, lBound)
+        E_pts.append(E); n_pts.append(n)
+        dE = E - E_pts[-2]
+        if abs(n) < conv:
+            break
+        counter += 1
+    if counter >= maxcycles:
+        print(f'Warning: Max cycles reached, convergence = {abs(n):.2E}')
+    return E, dE, P, abs(n), uBound, lBound

@@ -417,3 +417,95 @@ def calculate_current(F, S, sigma_calculator, fermi, qV, T=TEMPERATURE, spin=Non
     if spin == 'r':
         current_total *= 2
     return current_total
+
+
+# --------------------------------------------------------------------------- #
+# Legacy wrappers (gauNEGF/transport.py:724-1107): thin adapters kept so that existing
+# user scripts run unchanged; each one builds a SigmaCalculator and forwards to the
+# batch front-ends above (i.e. to the GPU engine).
+# --------------------------------------------------------------------------- #
+def _static_calc(sig1, sig2):
+    return SigmaCalculator(sig1, sig2, energy_dependent=False)
+
+
+def _dynamic_calc(g):
+    return SigmaCalculator(g, energy_dependent=True)
+
+
+def current(F, S, sig1, sig2, fermi, qV, T=TEMPERATURE, spin="r", dE=ENERGY_STEP):
+    """Coherent current, energy-independent self-energies (transport.py:724-770)."""
+    return calculate_current(F, S, _static_calc(sig1, sig2), fermi=fermi, qV=qV, T=T, spin=spin, dE=dE)
+
+
+def currentSpin(F, S, sig1, sig2, fermi, qV, T=TEMPERATURE, spin="r", dE=ENERGY_STEP):
+    """Spin currents [uu, ud, du, dd]; zeros for a restricted calculation (transport.py:772-812)."""
+    result = calculate_current(F, S, _static_calc(sig1, sig2), fermi=fermi, qV=qV, T=T, spin=spin, dE=dE)
+    return result[1] if isinstance(result, tuple) else [0, 0, 0, 0]
+
+
+def currentE(F, S, g, fermi, qV, T=TEMPERATURE, spin="r", dE=ENERGY_STEP):
+    """Coherent current with an energy-dependent provider ``g`` (transport.py:815-845)."""
+    return calculate_current(F, S, _dynamic_calc(g), fermi=fermi, qV=qV, T=T, spin=spin, dE=dE)
+
+
+def currentF(fn, dE=ENERGY_STEP, T=TEMPERATURE):
+    """Current from a saved SCF ``.mat`` file with keys F, S, sig1, sig2, fermi, qV, spin
+    (transport.py:847-875)."""
+    import scipy.io as io
+    m = io.loadmat(fn)
+    return current(m["F"], m["S"], m["sig1"], m["sig2"], m["fermi"][0, 0], m["qV"][0, 0], T, m["spin"][0], dE=dE)
+
+
+def _report(Elist, values, label, extra=None):
+    for i, E in enumerate(Elist):
+        if extra is None:
+            print("Energy:", E, f"eV, {label}=", values[i])
+        else:
+            print("Energy:", E, f"eV, {label}=", values[i], ", Tspin=", extra[i])
+
+
+def cohTrans(Elist, F, S, sig1, sig2):
+    """T(E) list, energy-independent self-energies (transport.py:878-912)."""
+    T_ = calculate_transmission(F, S, _static_calc(sig1, sig2), Elist, spin='r')
+    _report(Elist, T_, "Transmission")
+    return T_.tolist()
+
+
+def _spin_trans(Elist, F, S, calc, spin):
+    result = calculate_transmission(F, S, calc, Elist, spin=spin)
+    if isinstance(result, tuple):
+        T_, Ts = result
+        _report(Elist, T_, "Transmission", Ts)
+        return (T_.tolist(), Ts)
+    _report(Elist, result, "Transmission")
+    return (result.tolist(), np.zeros((len(Elist), 4)))
+
+
+def cohTransSpin(Elist, F, S, sig1, sig2, spin='u'):
+    """(T list, [M,4] spin-resolved T) (transport.py:914-966)."""
+    return _spin_trans(Elist, F, S, _static_calc(sig1, sig2), spin)
+
+
+def DOS(Elist, F, S, sig1, sig2):
+    """(DOS list, per-site DOS [M,N]) (transport.py:969-997)."""
+    tot, site = calculate_dos(F, S, _static_calc(sig1, sig2), Elist, spin='r')
+    return tot.tolist(), site
+
+
+def cohTransE(Elist, F, S, g):
+    """T(E) list with an energy-dependent provider (transport.py:1001-1034)."""
+    T_ = calculate_transmission(F, S, _dynamic_calc(g), Elist, spin='r')
+    _report(Elist, T_, "Transmission")
+    return T_.tolist()
+
+
+def cohTransSpinE(Elist, F, S, g, spin='u'):
+    """Spin-resolved T(E) with an energy-dependent provider (transport.py:1036-1075)."""
+    return _spin_trans(Elist, F, S, _dynamic_calc(g), spin)
+
+
+def DOSE(Elist, F, S, g):
+    """DOS with an energy-dependent provider (transport.py:1077-1107)."""
+    tot, site = calculate_dos(F, S, _dynamic_calc(g), Elist, spin='r')
+    _report(Elist, tot, "DOS")
+    return tot.tolist(), site

@@ -1,0 +1,113 @@
+"""
+Fermi-level searches and integration-limit fitting (SURVEY.md section 8 f-1;
+gauNEGF/density.py:821-1515): pure callers of the grid integrals.
+
+CPU part: the integrals are served by the oracle (monkeypatched GrInt / DOS kernel), which
+checks the host logic of the searches.  GPU part: the same searches on the HIP engine must
+land on the same Fermi level / grid sizes as the oracle-served run.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import gaunegf_amd.density as D
+from helpers import random_system, const_sigma_pair
+
+
+def _system(N=14, seed=11):
+    F, S = random_system(N, seed)
+    inds, s1, s2 = const_sigma_pair(N, S, 2, gamma=0.05)
+    return F, S, inds
+
+
+@pytest.fixture()
+def cpu_integrals(monkeypatch):
+    monkeypatch.setattr(D, "GrInt", oracle.GrInt)
+    monkeypatch.setattr(D, "GrLessInt", oracle.GrLessInt)
+    monkeypatch.setattr(D, "_compute_dos_at_energy", oracle.dos_at_energy)
+
+
+def _electrons(F, S, g, Emin, mu, N=64):
+    P = D.densityComplexN(F, S, g, Emin, mu, N, 0.0, showText=False)
+    return np.trace(P @ S).real
+
+
+def _run_searches(F, S, g, ne, Emin):
+    out = {}
+    out["secant"] = D.calcFermiSecant(g, ne, Emin, 0.0, 64, conv=1e-6, maxcycles=30, T=0.0)[0]
+    out["bisect"] = D.calcFermiBisect(g, ne, Emin, 0.0, 64, conv=1e-6, maxcycles=60, T=0.0)[0]
+    out["muller"] = D.calcFermiMuller(g, ne, Emin, 0.0, 64, conv=1e-6, maxcycles=30, T=0.0)[0]
+    out["polyfit"] = D.calcFermiPolyFit(g, ne, Emin, 0.0, 64, conv=1e-6, maxcycles=30, T=0.0)[0]
+    return out
+
+
+def test_searches_cpu(cpu_integrals, capsys):
+    F, S, inds = _system()
+    g = oracle.ConstSigma(F, S, inds, -0.05j)
+    Emin = D.calcEmin(F, S, g, tol=1e-3)
+    assert oracle.dos_at_energy(Emin, F, S, g.sigmaTot(Emin)) <= 1e-3
+    ne = 5.0
+    res = _run_searches(F, S, g, ne, Emin)
+    # calcFermiBisect mirrors the reference faithfully, including its bracketing quirk: after the
+    # bracket loop Ef is the last BOUND while Ncurr belongs to the last PROBE (density.py:1163-1185),
+    # so the bisection can collapse (uBound == lBound) -- only the other three must converge
+    for name, Ef in res.items():
+        if name != "bisect":
+            assert abs(_electrons(F, S, g, Emin, Ef) - ne) < 5e-5, name
+    good = [v for k, v in res.items() if k != "bisect"]
+    assert max(good) - min(good) < 1e-3 and np.isfinite(res["bisect"])
+    Emin2, N1, N2 = D.integralFit(F, S, g, res["secant"], Eminf=-50.0, tol=1e-3, T=0.0, maxN=300)
+    assert Emin2 == Emin and N1 >= 8 and N2 >= 16
+    Nn = D.integralFitNEGF(F, S, g, res["secant"], 0.2, tol=1e-3, T=300.0, maxGrid=300)
+    assert Nn >= 16
+
+
+def test_calcFermi_contact_cpu(cpu_integrals, capsys):
+    F, S, inds = _system(10, 3)
+    g = oracle.ConstSigma(F, S, inds, -0.05j)
+    fermi, Emin, N1, N2 = D.calcFermi(g, 4.0, -8.0, 3.0, 0.0, 32, 16, Eminf=-40.0, T=0.0, tol=1e-4, maxcycles=60)
+    P = np.real(D.densityRealN(F, S, g, -40.0, -8.0, 16, 0.0, showText=False) +
+                D.densityComplexN(F, S, g, -8.0, fermi, 32, 0.0, showText=False, method='legendre'))
+    assert abs(np.trace(P @ S) - 4.0) < 1e-3
+
+
+@pytest.mark.gpu
+def test_searches_gpu_match_oracle_run(engine, monkeypatch, capsys):
+    from gaunegf_amd.surfGTester import surfGTest
+    F, S, inds = _system()
+    ne = 5.0
+    g_dev = surfGTest(F, S, inds, -0.05j)
+    Emin_gpu = D.calcEmin(F, S, g_dev, tol=1e-3)
+    gpu = _run_searches(F, S, g_dev, ne, Emin_gpu)
+    fit_gpu = D.integralFit(F, S, g_dev, gpu["secant"], Eminf=-50.0, tol=1e-3, T=0.0, maxN=300)
+    # the same code served by the oracle
+    monkeypatch.setattr(D, "GrInt", oracle.GrInt)
+    monkeypatch.setattr(D, "GrLessInt", oracle.GrLessInt)
+    monkeypatch.setattr(D, "_compute_dos_at_energy", oracle.dos_at_energy)
+    g_ref = oracle.ConstSigma(F, S, inds, -0.05j)
+    Emin_ref = D.calcEmin(F, S, g_ref, tol=1e-3)
+    ref = _run_searches(F, S, g_ref, ne, Emin_ref)
+    fit_ref = D.integralFit(F, S, g_ref, ref["secant"], Eminf=-50.0, tol=1e-3, T=0.0, maxN=300)
+    assert Emin_gpu == Emin_ref
+    for k in ref:
+        assert abs(gpu[k] - ref[k]) < 1e-7, k
+    assert fit_gpu == fit_ref
+
+
+@pytest.mark.gpu
+def test_getFermi1DContact_gpu(engine, capsys):
+    """Lead Fermi level of a 2-orbital chain: runs integralFit + calcFermi on the device-side
+    CHAIN1D provider and returns a level inside the band with the requested filling."""
+    from gaunegf_amd.surfG1D import surfG
+    a = np.array([[0.0, 0.3], [0.3, 0.5]]); b = np.array([[-0.8, 0.1], [0.05, -0.6]])
+    N = 8
+    F = np.zeros((N, N)); S = np.eye(N)
+    for i in range(0, N, 2):
+        F[i:i + 2, i:i + 2] = a
+        if i + 2 < N:
+            F[i:i + 2, i + 2:i + 4] = b; F[i + 2:i + 4, i:i + 2] = b.T
+    z = np.zeros((2, 2)); I2 = np.eye(2)
+    g = surfG(F, S, [[0, 1], [N - 2, N - 1]], taus=[b.T, b], staus=[z, z], alphas=[a, a], aOverlaps=[I2, I2],
+              betas=[b.T, b], bOverlaps=[z, z], eta=1e-4)
+    fermi, Emin, N1, N2 = D.getFermi1DContact(g, 1, ind=0, tol=1e-2, Eminf=-30.0, T=0.0, maxcycles=40)
+    assert Emin < fermi < 3.0 and N1 >= 4 and N2 >= 8

@@ -204,6 +204,38 @@ def test_wire_current_symmetry(engine, golden_num):
     assert np.allclose(Tr, Tr[::-1], rtol=1e-9)
 
 
+def test_legacy_wrappers(engine, tmp_path, capsys):
+    """transport.py:724-1107 adapters: same numbers as the batch front-ends."""
+    import scipy.io as io
+    import gaunegf_amd.transport as T
+    N = 16
+    F, S = random_system(N, 5)
+    inds, s1, s2 = const_sigma_pair(N, S, 3)
+    E = np.linspace(-1, 1, 5)
+    sc = T.SigmaCalculator(s1, s2)
+    ref = T.calculate_transmission(F, S, sc, E)
+    assert np.array_equal(np.array(T.cohTrans(E, F, S, s1, s2)), ref)
+    tot, site = T.DOS(E, F, S, s1, s2)
+    tr, sr = T.calculate_dos(F, S, sc, E)
+    assert np.array_equal(np.array(tot), tr) and np.array_equal(site, sr)
+    I = T.current(F, S, s1, s2, 0.0, 0.1, dE=0.01)
+    assert I == T.calculate_current(F, S, sc, 0.0, 0.1, dE=0.01)
+    assert T.currentSpin(F, S, s1, s2, 0.0, 0.1, dE=0.01) == [0, 0, 0, 0]
+    fn = str(tmp_path / "scf.mat")
+    io.savemat(fn, {"F": F, "S": S, "sig1": s1, "sig2": s2, "fermi": 0.0, "qV": 0.1, "spin": "r"})
+    assert abs(T.currentF(fn, dE=0.01) - I) <= 1e-12 * abs(I)
+    # energy-dependent adapters with a device-side provider
+    from gaunegf_amd.surfGTester import surfGTest
+    g = surfGTest(F, S, inds, -0.1j)
+    assert np.allclose(T.cohTransE(E, F, S, g), ref, rtol=1e-12)
+    assert np.allclose(T.DOSE(E, F, S, g)[0], tr, rtol=1e-12)
+    assert abs(T.currentE(F, S, g, 0.0, 0.1, dE=0.01) - I) <= 1e-10 * abs(I)
+    Fu = np.kron(np.eye(2), F); Su = np.kron(np.eye(2), S)
+    Tt, Ts = T.cohTransSpin(E, Fu, Su, s1, s2, spin='u')
+    assert np.allclose(Ts[:, 0], ref, rtol=1e-9) and np.allclose(Ts[:, 3], ref, rtol=1e-9)
+    assert np.allclose(Ts[:, 1], 0, atol=1e-12) and np.allclose(Tt, 2 * ref, rtol=1e-9)
+
+
 @pytest.mark.parametrize("spin", ["u", "g"])
 def test_spin_block_transmission(engine, spin):
     from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
