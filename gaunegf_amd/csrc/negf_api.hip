@@ -197,6 +197,12 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
 {
     if (p->kind == SK_CHAIN1D) {
         ProfScope ps(c, "chain1d");
+        static int force_v1 = -1;
+        if (force_v1 < 0) { const char* e = getenv("NEGF_CHAIN1D_ALGO"); force_v1 = (e && strcmp(e, "global") == 0) ? 1 : 0; }
+        if (chain1d_lds_supported(p->nc_max) && !force_v1) {
+            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv);
+            return NEGF_OK;
+        }
         const size_t per = chain1d_scratch_per_wg(p->nc_max);
         const size_t need = per * p->n_contacts * nb;
         if (need > c->scratch_cap) {

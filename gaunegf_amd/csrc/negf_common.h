@@ -207,6 +207,10 @@ void launch_chain1d(hipStream_t st, const SigmaProvider& p, const int* d_nc, con
                     int nb, const cplx* E, cplx* blk, int* iters, int* conv, cplx* scratch,
                     size_t scratch_per_wg);
 size_t chain1d_scratch_per_wg(int nc_max);
+// LDS-resident MFMA version for n_c <= 64 (k_chain1d_lds.hip)
+bool chain1d_lds_supported(int nc_max);
+void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
+                        const cplx* E, cplx* blk, int* iters, int* conv);
 
 // Bethe lattice: one workgroup per (energy, contact); writes per-atom 9x9 blocks
 void launch_bethe(hipStream_t st, const SigmaProvider& p, int nb, const cplx* E, cplx* blk,
