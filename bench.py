@@ -102,6 +102,21 @@ def cpu_baseline(F, S, inds, E, w, budget_s=12.0):
                       f"(host has {ncpu} logical CPUs), {dt:.2f} s"}
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per inverse launch from the committed PMC profile of this same command
+    (profiles/r01_pmc/..., separate --pmc passes): 2 x FETCH_SIZE (gfx950 reports half of a
+    wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc", "c2_bench_pmc_per_launch_avg.json")
+    try:
+        data = json.load(open(path))
+        for name, ctr in data.items():
+            if "gj_blocked_kernel" in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +227,9 @@ def main():
                        "n_orb": N, "energies_per_gpu": M, "sharding": f"energy-cyclic x{world}",
                        "density_matrix_wall_ms": dt / args.steps * 1e3},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": pmc_traffic_bytes()[0], "traffic_source": pmc_traffic_bytes()[1],
+                         "algorithmic_bytes_per_launch": 2.0 * 16.0 * N * N * pts_per_launch,
                          "kernel": "inverse (blocked Gauss-Jordan)",
                          "avg_launch_ms": avg_launch_ms, "launches": launches,
                          "flops_per_point": flops_per_launch_pt,

@@ -39,6 +39,14 @@ def _callback_chunks(n, m, per_energy_mats):
     return [(a, min(a + step, m)) for a in range(0, m, step)]
 
 
+def _sigma_tot_stack(g, E):
+    """[m,n,n] host-evaluated Sigma_tot; providers may offer a vectorised ``sigmaTot_batch``
+    (one GPU launch for all energies, e.g. surfGBAt) instead of one call per energy."""
+    if hasattr(g, "sigmaTot_batch"):
+        return np.asarray(g.sigmaTot_batch(E))
+    return np.stack([np.asarray(g.sigmaTot(e)) for e in E])
+
+
 def _partial_gr(engine, g, E, w):
     """sum over the given energies on this process's GPU."""
     if E.size == 0:
@@ -47,7 +55,7 @@ def _partial_gr(engine, g, E, w):
         return engine.gr_int(g._negf_lower(engine), E, w)
     acc = np.zeros((engine.n, engine.n), dtype=np.complex128)
     for a, b in _callback_chunks(engine.n, E.size, 1):
-        sig = np.stack([np.asarray(g.sigmaTot(e)) for e in E[a:b]])
+        sig = _sigma_tot_stack(g, E[a:b])
         h = engine.sigma_precomputed(sig)
         try:
             acc += engine.gr_int(h, E[a:b], w[a:b])
@@ -63,7 +71,7 @@ def _partial_gless(engine, g, E, w, ind):
         return engine.gless_int(g._negf_lower(engine), ind, E, w)
     acc = np.zeros((engine.n, engine.n), dtype=np.complex128)
     for a, b in _callback_chunks(engine.n, E.size, 1 if ind is None else 2):
-        sig = np.stack([np.asarray(g.sigmaTot(e)) for e in E[a:b]])
+        sig = _sigma_tot_stack(g, E[a:b])
         sig_c = None if ind is None else np.stack([np.asarray(g.sigma(e, ind)) for e in E[a:b]])
         h = engine.sigma_precomputed(sig, sig_c)
         try:
@@ -119,7 +127,7 @@ def GrBatch(F, S, g, Elist):
         return engine.gr_batch(g._negf_lower(engine), E)
     out = np.zeros((E.size, engine.n, engine.n), dtype=np.complex128)
     for a, b in _callback_chunks(engine.n, E.size, 1):
-        sig = np.stack([np.asarray(g.sigmaTot(e)) for e in E[a:b]])
+        sig = _sigma_tot_stack(g, E[a:b])
         h = engine.sigma_precomputed(sig)
         try:
             out[a:b] = engine.gr_batch(h, E[a:b])

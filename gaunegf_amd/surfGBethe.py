@@ -202,6 +202,17 @@ class surfGBAt:
             sig[blk, blk] = tot - sigK[(k + 6) % 12]
         return sig
 
+    def sigmaTot_batch(self, Elist, conv=SURFACE_GREEN_CONVERGENCE):
+        """[M,117,117] cluster self-energies from ONE launch of the Bethe kernel (used by the
+        grid integrals of the contact Fermi-level search)."""
+        sigK = self.sigmaK(np.asarray(Elist), conv)                     # [M,12,9,9]
+        tot = np.sum(sigK, axis=1)
+        out = np.zeros((sigK.shape[0], (self.NN + 1) * dim, (self.NN + 1) * dim), dtype=complex)
+        for k in range(self.NN):
+            blk = slice(k * dim, (k + 1) * dim)
+            out[:, blk, blk] = tot - sigK[:, (k + 6) % 12]
+        return out
+
     def DOS(self, E):
         """Bulk DOS of the lattice, -Im Tr G / pi with G = inv((E - i eta) - H - sum sigma(E))
         (surfGBethe.py:1139-1155)."""

