@@ -210,7 +210,9 @@ template <int NB, int CPR, int RPT>
 __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
     int dbg /* ablation switches, 0 in production: 2 = no MFMA, 4 = no tile loads, 16 = U-team idle,
-               32 = no pivot steps */)
+               32 = no pivot steps */,
+    unsigned long long* __restrict__ stamps /* diagnostic build only (NEGF_GJ_STAMPS): wall-clock
+               stamps of workgroup 0, [step+1][8]; nullptr in production */)
 {
     using C = GjCfg<NB, CPR, RPT>;
     constexpr int S = C::S, TPR = C::TPR;
@@ -248,6 +250,10 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 
     const int fi = lane & 15, fk = lane >> 4;
     const int tiles = rows16 >> 4;
+    auto stamp = [&](int step, int slot, int w) __attribute__((always_inline)) {
+        if (stamps && blockIdx.x == 0 && wave == w && lane == 0)
+            stamps[(size_t)(step + 1) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    };
 
     // ---- panel factorisation of block column [p0, p0+pw) by the P-team: strips in registers,
     // result written to the panel columns of the matrix (nobody else touches them meanwhile)
@@ -408,7 +414,9 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                 }
             }
             if (tid == 0) next_item = 0;
+            stamp(step, 0, 0);
             __syncthreads();             // [A] Pt, Q snapshot visible; pivot rows of W are not read again
+            stamp(step, 1, 0);
         }
         if (has_cur && has_next) {
             // ---- every wave: apply step s to the columns of block column s+1 first (look-ahead)
@@ -420,11 +428,14 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                 if (part * rq < tiles)
                     update_item(k0, kw, tj, part * rq, min(tiles, part * rq + rq), n0, n0 + nw, true);
             }
+            stamp(step, 2, 0);
             __syncthreads();             // [A2] block column s+1 is up to date
+            stamp(step, 3, 0);
         }
         // ---- P-team: factor block column s+1; U-team: update the other columns.  The update items
         // come from a shared queue, so the P-team joins in as soon as its panel is done.
         if (pwave && has_next) factor_panel(n0, nw);
+        stamp(step, 4, 0);
         if (has_cur && !((dbg & 16) && has_next)) {
             const int rhalf = (tiles + 1) >> 1;
             while (true) {
@@ -440,7 +451,10 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                             has_next ? n0 : 0, has_next ? n0 + nw : 0, false);
             }
         }
+        stamp(step, 5, 0);
+        stamp(step, 6, PW);              // a U-team wave: end of its update work
         __syncthreads();                 // [B] step complete everywhere; block column s+1 factored
+        stamp(step, 7, 0);
     }
     if (tid == 0) info[blockIdx.x] = bad_sh;
     // ---------------- G[i][j] = W[pivrow[i]][colof[j]] : four rows per wave iteration,
@@ -495,8 +509,28 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
         attr_set = true;
     }
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("NEGF_GJ_DEBUG"); dbg = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg);
+    static unsigned long long* d_stamps = nullptr;
+    if (dbg < 0) {
+        const char* e = getenv("NEGF_GJ_DEBUG"); dbg = e ? atoi(e) : 0;
+        if (getenv("NEGF_GJ_STAMPS")) {
+            (void)hipMalloc(&d_stamps, 64 * 8 * sizeof(unsigned long long));
+            (void)hipMemset(d_stamps, 0, 64 * 8 * sizeof(unsigned long long));
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg, d_stamps);
+    if (d_stamps) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[64 * 8];
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        const int np = (n + NB - 1) / NB;
+        fprintf(stderr, "[gj stamps] 100 MHz ticks relative to step start; cols: A-in A-out A2-in A2-out panel-done upd-done(P) upd-done(U) B-out\n");
+        unsigned long long t0 = h[7];
+        for (int sidx = 0; sidx <= np; ++sidx) {
+            fprintf(stderr, "[gj stamps] step %2d:", sidx - 1);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %8.2f", h[sidx * 8 + k] ? (double)(h[sidx * 8 + k] - t0) / 100.0 : -1.0);
+            fprintf(stderr, "  (us since end of step -1)\n");
+        }
+    }
 }
 
 // which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
