@@ -46,114 +46,182 @@
 
 namespace {
 
-constexpr int GJB_THREADS = 768;
-constexpr int GJB_WAVES = GJB_THREADS / 64;
-constexpr int PW = 8;                              // panel-team waves
-constexpr int PT = PW * 64;                        // panel threads
-
-template <int NB, int CPR, int RPT>
+// NB panel width, CPR strips per panel row, RPT rows per panel thread, PW panel-team waves,
+// NW waves of the workgroup (the NW - PW others only do trailing updates)
+template <int NB_, int CPR_, int RPT_, int PW_, int NW_>
 struct GjCfg {
+    static constexpr int NB = NB_, CPR = CPR_, RPT = RPT_, PW = PW_, NW = NW_;
+    static constexpr int PT = PW * 64;             // panel threads
+    static constexpr int THREADS = NW * 64;
     static constexpr int S = NB / CPR;             // complex values per strip (1/CPR of a panel row)
-    static constexpr int TPR = PT / CPR;           // panel threads along the row dimension
+    static constexpr int LPR = 64 / CPR;           // rows per wave and slab: the CPR strips of a row sit in
+                                                   // ONE wave, at lanes  l, l + LPR, ...
+    static constexpr int TPR = PW * LPR;           // rows per slab (= PT / CPR)
     static constexpr int ROWS = TPR * RPT;         // row capacity
-    static constexpr int WPG = PW / CPR;           // waves per column part (owner group of a column)
 };
 
-struct RedSlot { double v; int key; int pad; };
-
-// ---- team barrier: an LDS counter (monotonic), release/acquire at workgroup scope ----
+// ---- team barrier on an LDS counter (monotonic).  All data the team exchanges lives in LDS and
+// the DS instructions of a wave execute in issue order, so the counter increment is performed
+// after the wave's earlier LDS writes without waiting for them to return (no release wait);
+// the reads that follow are issued after the polling read has returned (no acquire action).
+// The asm statements only stop the compiler from moving memory operations across the barrier.
+template <int PW>
 __device__ __forceinline__ void team_sync(int* ctr, int& expect, int lane)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("" ::: "memory");
     expect += PW;
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect)
-        __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) { }
+    asm volatile("" ::: "memory");
 }
 
-constexpr int KEY_NONE = 0x7fffffff;
+typedef unsigned long long u64;
+
+// Pivot candidates are ordered by ONE 64-bit integer: the upper 48 bits of |value| (as a
+// non-negative double, so integer order == numeric order) over 16 bits of (0xFFFF - row):
+// larger magnitude wins, equal magnitudes (to 36 mantissa bits) go to the lower row.  0 = no
+// candidate (no available row, or only NaNs).  Deterministic; a pivot within 2^-36 of the column
+// maximum is as good as the maximum for the growth bound.
+__device__ __forceinline__ u64 cand_key(double v, int row)
+{
+    return ((u64)__double_as_longlong(v) & ~0xFFFFull) | (u64)(0xFFFF - row);
+}
+
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_max_u64(u64 k)
+{
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    const u64 o = ((u64)ohi << 32) | olo;
+    return o > k ? o : k;
+}
+
+// maximum over the 64 lanes, returned wave-uniform.  All lanes must be active.
+__device__ __forceinline__ u64 wave_max_u64(u64 k)
+{
+    k = dpp_max_u64<0xB1>(k);      // quad_perm [1,0,3,2]
+    k = dpp_max_u64<0x4E>(k);      // quad_perm [2,3,0,1]
+    k = dpp_max_u64<0x141>(k);     // row_half_mirror
+    k = dpp_max_u64<0x140>(k);     // row_mirror -> every lane of a row of 16 holds the row maximum
+    u64 best = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, r * 16);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), r * 16);
+        const u64 o = ((u64)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    return best;
+}
 
 // ---- one Gauss-Jordan column step on the register strips (P-team only), J compile-time ----
-template <int NB, int CPR, int RPT>
+// ONE team barrier per column: before the barrier every wave publishes its best pivot candidate
+// for the next column (an LDS atomic max on the candidate key) TOGETHER with that candidate's whole
+// (already updated) panel row; after the barrier every thread reads the winning key and the
+// winner's row -- there is no second "owner publishes the pivot row" round trip.  Candidate rows
+// are double buffered by column parity and the key slots triple buffered, so a fast wave
+// publishing for column J+1 never disturbs what a slow wave still reads for column J.
+template <class C>
 struct PanelCtx {
-    cplx (&a)[RPT][NB / CPR];
-    bool (&avail)[RPT];              // row not used as a pivot yet
-    cplx* rowbuf; cplx* colbuf; RedSlot* red; cplx* piv_ip; int* bad_sh;
+    cplx (&a)[C::RPT][C::S];
+    bool (&avail)[C::RPT];           // row not used as a pivot yet
+    cplx* cand;                      // [2][PW][NB] candidate pivot rows
+    u64* slot;                       // [3] winning candidate key of a column
+    int* bad_sh;
     int* pivrow; int* colof; int* team_ctr; int& team_expect;
-    int n, k0, kw, tid, lane, wave, h, tr, wave_tr0;
+    int n, k0, kw, tid, lane, wave, h, tr;
+    unsigned long long* st;          // diagnostic stamps (nullptr in production)
 };
 
-template <int NB, int CPR, int RPT, int J>
+template <class C>
+__device__ __forceinline__ void pstamp(PanelCtx<C>& x, int slot)
+{
+    if (x.st && x.tid == 0) x.st[slot] = __builtin_amdgcn_s_memrealtime();
+}
+
+// col: panel-relative column whose pivot is sought; its entries sit at strip position sn of part hn
+template <class C>
+__device__ __forceinline__ void publish_candidate(PanelCtx<C>& x, int col, int hn, int sn)
+{
+    constexpr int NB = C::NB, RPT = C::RPT, PW = C::PW, S = C::S, TPR = C::TPR;
+    u64 key = 0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int r = x.tr + q * TPR;
+        const double v = cabs1(x.a[q][sn]);
+        const bool mine = (x.h == hn) & (r < x.n) & x.avail[q] & (v == v);
+        const u64 k = mine ? cand_key(v, r) : 0ull;
+        key = k > key ? k : key;
+    }
+    key = wave_max_u64(key);
+    const int brow = 0xFFFF - (int)(key & 0xFFFFull);           // meaningless when key == 0
+    cplx* cn = x.cand + ((size_t)((col & 1) * PW + x.wave)) * NB + x.h * S;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+        if (key != 0 && x.tr + q * TPR == brow) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) cn[s] = x.a[q][s];
+        }
+    if (x.lane == 0 && key != 0)
+        __hip_atomic_fetch_max(x.slot + col % 3, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <class C, int J>
 struct PanelSteps {
-    static __device__ __forceinline__ void run(PanelCtx<NB, CPR, RPT>& x)
+    static __device__ __forceinline__ void run(PanelCtx<C>& x)
     {
-        using C = GjCfg<NB, CPR, RPT>;
-        constexpr int S = C::S, TPR = C::TPR, WPG = C::WPG;
+        constexpr int NB = C::NB, CPR = C::CPR, RPT = C::RPT, PW = C::PW;
+        constexpr int S = C::S, TPR = C::TPR, LPR = C::LPR;
         constexpr int hj = J / S, sj = J % S;
         if (J < x.kw) {                                     // uniform branch
             const int c = x.k0 + J;
-            // (1) combine the partials published by the waves that own column J
-            const RedSlot* red = x.red + (J & 1) * PW + hj * WPG;
-            double wv = red[0].v; int pphys = red[0].key;
-#pragma unroll
-            for (int w = 1; w < WPG; ++w) {
-                const double ov = red[w].v; const int ok = red[w].key;
-                const bool take = (ov > wv) | ((ov == wv) & (ok < pphys));
-                wv = take ? ov : wv; pphys = take ? ok : pphys;
-            }
-            if (!(wv > 0.0) && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;   // singular / NaN
-            // a column of NaNs yields no candidate (the same for every wave of the team): fall back
-            // to the lowest still-available row so the bookkeeping stays a permutation
-            if (pphys == KEY_NONE) {
-                if (x.tid == 0) x.red[0].pad = KEY_NONE;
-                team_sync(x.team_ctr, x.team_expect, x.lane);
-#pragma unroll
-                for (int q = 0; q < RPT; ++q) {
-                    const int r = x.tr + q * TPR;
-                    if (x.h == 0 && r < x.n && x.avail[q]) atomicMin(&x.red[0].pad, r);
-                }
-                team_sync(x.team_ctr, x.team_expect, x.lane);
-                pphys = x.red[0].pad;
-                team_sync(x.team_ctr, x.team_expect, x.lane);
-            }
-            // (2) publish the unscaled pivot row, 1/pivot and the pivot column
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = x.tr + q * TPR;
-                if (r == pphys) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s) x.rowbuf[x.h * S + s] = x.a[q][s];
-                    if (x.h == hj) {
-                        // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the
-                        // overflow range for these matrices)
-                        const cplx pv = x.a[q][sj];
-                        const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
-                        *x.piv_ip = cmake(pv.x * sc, -pv.y * sc);
-                    }
-                }
-                if (x.h == hj) x.colbuf[r] = x.a[q][sj];
-            }
-            if (x.tid == 0) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
-            team_sync(x.team_ctr, x.team_expect, x.lane);
-            // (3) rank-1 update of every strip in sub-strips of 8 (bounded register use): a batch
-            //     of LDS reads of the pivot row part, then register arithmetic
-            const cplx ip = *x.piv_ip;
+            pstamp(x, 300 + J);
+            // (1) the winning candidate.  key == 0: no usable row (a column of NaNs) -- the step
+            // then runs with no pivot row (nothing is indexed by it) and the matrix is reported
+            // through info; (key >> 16) == 0: the column maximum is exactly zero (singular).
+            const u64 key = x.slot[J % 3];
+            const bool none = key == 0;
+            const int pphys = none ? -1 : 0xFFFF - (int)(key & 0xFFFFull);
+            const int ww = none ? 0 : (pphys % TPR) / LPR;
+            if ((key >> 16) == 0 && x.tid == 0 && *x.bad_sh == 0) *x.bad_sh = c + 1;
+            if (x.tid == 0) x.slot[(J + 2) % 3] = 0;        // slot of column J+2: last read in step J-1
+            if constexpr (J == 4) pstamp(x, 340);
+            // (2) the winner's row part for my columns, 1/pivot (computed by every thread)
+            const cplx* prow = x.cand + (size_t)((J & 1) * PW + ww) * NB;
+            const cplx pv = prow[J];
+            // 1/pivot = conj(pivot) / |pivot|^2 (one division; |pivot| is far from the overflow
+            // range for these matrices)
+            const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+            const cplx ip = cmake(pv.x * sc, -pv.y * sc);
+            // (3) -(f / pivot) with f = my row's entry of column J, held by the lane of part hj
             cplx nfm[RPT];
 #pragma unroll
-            for (int q = 0; q < RPT; ++q) nfm[q] = cneg(cmul(x.colbuf[x.tr + q * TPR], ip));   // -(f / pivot)
+            for (int q = 0; q < RPT; ++q) {
+                cplx f = x.a[q][sj];
+                if constexpr (CPR > 1) {
+                    const int src = (x.lane % LPR) + hj * LPR;
+                    f.x = __shfl(f.x, src, 64);
+                    f.y = __shfl(f.y, src, 64);
+                }
+                nfm[q] = cneg(cmul(f, ip));
+            }
+            if constexpr (J == 4) pstamp(x, 341);
+            if (x.tid == 0 && !none) { x.pivrow[c] = pphys; x.colof[pphys] = c; }
             bool wave_has_piv = false;
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const int d = pphys - q * TPR - x.wave_tr0;
-                wave_has_piv |= (d >= 0 && d < 64);
+                const int d = pphys - q * TPR - x.wave * LPR;
+                wave_has_piv |= (d >= 0 && d < LPR);
             }
+            // (4) rank-1 update of every strip in sub-strips of 8 (bounded register use): a batch
+            //     of LDS reads of the pivot row part, then register arithmetic
             constexpr int HS = (S >= 8) ? 8 : S;
 #pragma unroll
             for (int s0 = 0; s0 < S; s0 += HS) {
                 cplx rb[HS];
 #pragma unroll
-                for (int s = 0; s < HS; ++s) rb[s] = x.rowbuf[x.h * S + s0 + s];
+                for (int s = 0; s < HS; ++s) rb[s] = prow[x.h * S + s0 + s];
                 if (!wave_has_piv) {
                     // select-free path: row <- row - (f/pivot) * pivot row
 #pragma unroll
@@ -181,65 +249,119 @@ struct PanelSteps {
                 if (x.h == hj) x.a[q][sj] = is_piv ? ip : nfm[q];
                 x.avail[q] = x.avail[q] && !is_piv;
             }
-            // (4) pivot search for column J+1 on the freshly updated strips (its owner waves)
+            if constexpr (J == 4) pstamp(x, 342);
+            // (5) candidates for column J+1 from the freshly updated strips
             if constexpr (J + 1 < NB) {
-                constexpr int hn = (J + 1) / S, sn = (J + 1) % S;
-                if (x.h == hn && J + 1 < x.kw) {            // wave-uniform: a wave belongs to one column part
-                    double bv = -1.0; int bkey = KEY_NONE;
-#pragma unroll
-                    for (int q = 0; q < RPT; ++q) {
-                        const int r = x.tr + q * TPR;
-                        if (r < x.n && x.avail[q]) {
-                            const double v = cabs1(x.a[q][sn]);
-                            const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                            bv = take ? v : bv; bkey = take ? r : bkey;
-                        }
-                    }
-                    wave_argmax(bv, bkey);
-                    RedSlot* rn = x.red + ((J + 1) & 1) * PW;
-                    if (x.lane == 0) { rn[x.wave].v = bv; rn[x.wave].key = bkey; }
-                }
+                if (J + 1 < x.kw) publish_candidate<C>(x, J + 1, (J + 1) / S, (J + 1) % S);
             }
-            team_sync(x.team_ctr, x.team_expect, x.lane);
-            if constexpr (J + 1 < NB) PanelSteps<NB, CPR, RPT, J + 1>::run(x);
+            if constexpr (J == 4) pstamp(x, 343);
+            team_sync<PW>(x.team_ctr, x.team_expect, x.lane);
+            if constexpr (J == 4) pstamp(x, 344);
+            // last column of the panel: every wave has read its slot by now; leave all three zero
+            if (J + 1 >= x.kw && x.tid == 0) x.slot[J % 3] = 0;
+            if constexpr (J + 1 < NB) PanelSteps<C, J + 1>::run(x);
         }
     }
 };
 
-template <int NB, int CPR, int RPT>
-__global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
+// ---- trailing update of one (column tile tj, row tiles [ti0, ti1)) item with the panel in LDS:
+//        W[i][col] = (i pivot row of this panel ? 0 : W[i][col]) + sum_k P[i][k] * Q[k][col]
+// Q fragments stay in registers for the whole item, P comes from LDS (k-major), the C tile of the
+// next row tile is in flight while the current one runs its MFMAs.  All loads are unconditional on
+// clamped (always valid) addresses and masked by selects afterwards: no divergent branches in the
+// loop, so the loads of the next tile really stay outstanding across the MFMAs.  Always KS k-steps:
+// rows k >= kw of P and Q are zero.  Stores go to columns with lo <= col < hi (inside) or to the
+// others (!inside), never to the panel's own columns.
+template <int KS>
+__device__ __forceinline__ void gj_update_item(const cplx* __restrict__ Pt, int rows16, cplx* W, const cplx* X,
+                                               const unsigned* rowmask, int n, int k0, int kw, int tj, int ti0,
+                                               int ti1, int st_lo, int st_hi, bool inside, int lane)
+{
+    const int fi = lane & 15, fk = lane >> 4;
+    const int col = tj * 16 + fi;
+    const bool col_ok = col < n;
+    const int colc = col_ok ? col : n - 1;
+    const bool in_rng = col >= st_lo && col < st_hi;
+    const bool col_store = col_ok && !(col >= k0 && col < k0 + kw) && (inside ? in_rng : !in_rng);
+    cplx qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = ks * 4 + fk;
+        const cplx v = X[(size_t)(k < kw ? k : kw - 1) * n + colc];
+        const bool ok = (k < kw) & col_ok;
+        qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
+    }
+    const cplx* wcol = W + colc;
+    cplx c0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c0[r] = wcol[(size_t)min(ti0 * 16 + fk + 4 * r, n - 1) * n];
+    for (int ti = ti0; ti < ti1; ++ti) {
+        const unsigned m = rowmask[ti >> 1] >> ((ti & 1) * 16 + fk);    // bit 4r: row fk + 4r of this tile
+        d4 accr, acci;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool z = (m >> (4 * r)) & 1u;
+            accr[r] = z ? 0.0 : c0[r].x; acci[r] = z ? 0.0 : c0[r].y;
+        }
+        const int tn = min(ti + 1, ti1 - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c0[r] = wcol[(size_t)min(tn * 16 + fk + 4 * r, n - 1) * n];
+        const cplx* pcol = Pt + (size_t)fk * rows16 + ti * 16 + fi;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const cplx pa = pcol[(size_t)ks * 4 * rows16];
+            accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
+            accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
+            acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].y, acci, 0, 0, 0);
+            acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].x, acci, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + fk + 4 * r;
+            if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+        }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
     int dbg /* ablation switches, 0 in production: 2 = no MFMA, 4 = no tile loads, 16 = U-team idle,
                32 = no pivot steps */,
     unsigned long long* __restrict__ stamps /* diagnostic build only (NEGF_GJ_STAMPS): wall-clock
                stamps of workgroup 0, [step+1][8]; nullptr in production */)
 {
-    using C = GjCfg<NB, CPR, RPT>;
+    constexpr int NB = C::NB, RPT = C::RPT, PW = C::PW;
+    constexpr int GJB_THREADS = C::THREADS, GJB_WAVES = C::NW, PT = C::PT;
     constexpr int S = C::S, TPR = C::TPR;
     constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int rows16 = (n + 15) & ~15;
     cplx* Pt = reinterpret_cast<cplx*>(smem_raw);                // [NB][rows16]  P, k-major, physical rows
-    cplx* rowbuf = Pt + (size_t)NB * rows16;                     // [NB]   unscaled pivot row
-    cplx* colbuf = rowbuf + NB;                                  // [ROWS] pivot column
-    int* pivrow = reinterpret_cast<int*>(colbuf + C::ROWS);      // [rows16] physical pivot row of column c
+    cplx* cand = Pt + (size_t)NB * rows16;                       // [2][PW][NB] candidate pivot rows
+    int* pivrow = reinterpret_cast<int*>(cand + 2 * PW * NB);    // [rows16] physical pivot row of column c
     int* colof = pivrow + rows16;                                // [rows16] column a row was pivot for, or -1
-    __shared__ RedSlot red[2][PW];
-    __shared__ cplx piv_ip;
+    __shared__ u64 slot[3];
     __shared__ int bad_sh;
     __shared__ int team_ctr;
     __shared__ int next_item;        // work queue of the update items of the current step
+    __shared__ unsigned rowmask[16]; // bit r: row r was a pivot row of the current panel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool pwave = wave < PW;
-    const int h = (tid % PT) / TPR;          // column part of the panel held by this thread (wave-uniform)
-    const int tr = (tid % PT) - h * TPR;     // row slot
+    const int h = lane / C::LPR;                              // column part of the panel row held by this lane
+    const int tr = (wave % PW) * C::LPR + lane % C::LPR;      // row slot
     cplx* W = bufA + (size_t)blockIdx.x * mat_stride;            // the matrix, updated in place
     cplx* X = bufB + (size_t)blockIdx.x * mat_stride;            // Q snapshots, then the result
     int team_expect = 0;
 
     if (tid == 0) { bad_sh = 0; team_ctr = 0; }
+    if (tid < 3) slot[tid] = 0;
+    if (stamps && blockIdx.x == 0 && tid == 0) {
+        stamps[400] = __builtin_amdgcn_s_memrealtime();
+        stamps[401] = __builtin_amdgcn_s_memtime();
+    }
     for (int t = tid; t < rows16; t += GJB_THREADS) { colof[t] = -1; pivrow[t] = 0; }
     // rows >= n of P stay zero for the whole kernel (A operand of the edge tiles)
     for (int t = tid; t < NB * (rows16 - n); t += GJB_THREADS) {
@@ -270,26 +392,15 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
             for (int s = 0; s < S; ++s)
                 a[q][s] = (row_ok && h * S + s < pw) ? g[s] : cmake(0.0, 0.0);
         }
-        if (h == 0) {                                       // waves owning column 0 of the panel
-            double bv = -1.0; int bkey = KEY_NONE;
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = tr + q * TPR;
-                if (r < n && avail[q]) {
-                    const double v = cabs1(a[q][0]);
-                    const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                    bv = take ? v : bv; bkey = take ? r : bkey;
-                }
-            }
-            wave_argmax(bv, bkey);
-            if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
-        }
-        team_sync(&team_ctr, team_expect, lane);
+        // the slots were left at zero by the previous panel (every column resets the slot two ahead;
+        // the last two columns of a panel publish nothing into theirs)
+        PanelCtx<C> ctx{a, avail, cand, slot, &bad_sh, pivrow, colof,
+                                   &team_ctr, team_expect, n, p0, pw, tid, lane, wave, h, tr,
+                                   (stamps && blockIdx.x == 0 && p0 == 2 * NB) ? stamps : nullptr};
+        publish_candidate<C>(ctx, 0, 0, 0);
+        team_sync<PW>(&team_ctr, team_expect, lane);
         if (!(dbg & 32)) {
-            PanelCtx<NB, CPR, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
-                                       &team_ctr, team_expect, n, p0, pw, tid, lane, wave, h, tr,
-                                       (tid & ~63) - h * TPR};
-            PanelSteps<NB, CPR, RPT, 0>::run(ctx);
+            PanelSteps<C, 0>::run(ctx);
         } else if (tid == 0) {
             for (int j = 0; j < pw; ++j) { pivrow[p0 + j] = p0 + j; colof[p0 + j] = p0 + j; }
         }
@@ -301,61 +412,6 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 #pragma unroll
                 for (int s = 0; s < S; ++s)
                     if (h * S + s < pw) g[s] = a[q][s];
-            }
-        }
-    };
-
-    // ---- trailing update of one (column tile, row-tile range) item for the panel [k0, k0+kw):
-    // stores only columns with  lo <= col < hi  XOR outside (mode): see callers
-    auto update_item = [&](int k0, int kw, int tj, int ti0, int ti1, int st_lo, int st_hi,
-                           bool inside) __attribute__((always_inline)) {
-        const int col = tj * 16 + fi;
-        const bool col_ok = col < n;
-        const bool in_rng = col >= st_lo && col < st_hi;
-        const bool col_store = col_ok && !(col >= k0 && col < k0 + kw) && (inside ? in_rng : !in_rng);
-        cplx qf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = ks * 4 + fk;
-            qf[ks] = cmake(0.0, 0.0);
-            if (k < kw && col_ok && !(dbg & 4)) qf[ks] = X[(size_t)k * n + col];
-        }
-        // the next C tile is prefetched while the current one runs its MFMAs; rows used as
-        // pivots in this panel start from zero
-        auto load_c = [&](int ti, cplx (&dst)[4]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                dst[r] = cmake(0.0, 0.0);
-                if (ti < ti1 && i < n && col_ok && !(dbg & 4)) {
-                    const int cf = colof[i];
-                    if (!(cf >= k0 && cf < k0 + kw)) dst[r] = W[(size_t)i * n + col];
-                }
-            }
-        };
-        cplx c0[4];
-        load_c(ti0, c0);
-        for (int ti = ti0; ti < ti1; ++ti) {
-            d4 accr, acci;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { accr[r] = c0[r].x; acci[r] = c0[r].y; }
-            load_c(ti + 1, c0);
-            const cplx* pcol = Pt + (size_t)fk * rows16 + ti * 16 + fi;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks * 4 < kw) {
-                    const cplx pa = pcol[(size_t)ks * 4 * rows16];
-                    if (dbg & 2) { accr[0] += pa.x * qf[ks].x; acci[0] += pa.y * qf[ks].y; continue; }
-                    accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
-                    accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
-                    acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].y, acci, 0, 0, 0);
-                    acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].x, acci, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
             }
         }
     };
@@ -414,6 +470,15 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                 }
             }
             if (tid == 0) next_item = 0;
+            if (tid >= GJB_THREADS - 16) {               // 16 lanes of the last wave: 32 rows each
+                const int t = tid - (GJB_THREADS - 16);
+                unsigned m = 0;
+                for (int b = 0; b < 32; ++b) {
+                    const int r = t * 32 + b;
+                    if (r < n) { const int cf = colof[r]; m |= (cf >= k0 && cf < k0 + kw) ? (1u << b) : 0u; }
+                }
+                rowmask[t] = m;
+            }
             stamp(step, 0, 0);
             __syncthreads();             // [A] Pt, Q snapshot visible; pivot rows of W are not read again
             stamp(step, 1, 0);
@@ -426,7 +491,8 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
             for (int item = wave; item < (t_hi - t_lo) * nq; item += GJB_WAVES) {
                 const int tj = t_lo + item / nq, part = item % nq;
                 if (part * rq < tiles)
-                    update_item(k0, kw, tj, part * rq, min(tiles, part * rq + rq), n0, n0 + nw, true);
+                    gj_update_item<KS>(Pt, rows16, W, X, rowmask, n, k0, kw, tj, part * rq, min(tiles, part * rq + rq), n0,
+                                       n0 + nw, true, lane);
             }
             stamp(step, 2, 0);
             __syncthreads();             // [A2] block column s+1 is up to date
@@ -447,8 +513,8 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
                 const int c_lo = tj * 16, c_hi = min(n, c_lo + 16);
                 if (c_lo >= k0 && c_hi <= k0 + kw) continue;                         // inside block column s
                 if (has_next && c_lo >= n0 && c_hi <= n0 + nw) continue;             // done in the look-ahead
-                update_item(k0, kw, tj, part ? rhalf : 0, part ? tiles : rhalf,
-                            has_next ? n0 : 0, has_next ? n0 + nw : 0, false);
+                gj_update_item<KS>(Pt, rows16, W, X, rowmask, n, k0, kw, tj, part ? rhalf : 0, part ? tiles : rhalf,
+                                   has_next ? n0 : 0, has_next ? n0 + nw : 0, false, lane);
             }
         }
         stamp(step, 5, 0);
@@ -457,6 +523,14 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
         stamp(step, 7, 0);
     }
     if (tid == 0) info[blockIdx.x] = bad_sh;
+    // a singular (or NaN) matrix has no inverse: its result is NaN-filled and the pivot
+    // bookkeeping, possibly incomplete, is not used as an index
+    const bool dead = bad_sh != 0;
+    const double fillv = __builtin_nan("");
+    if (stamps && blockIdx.x == 0 && tid == 0) {
+        stamps[402] = __builtin_amdgcn_s_memrealtime();
+        stamps[403] = __builtin_amdgcn_s_memtime();
+    }
     // ---------------- G[i][j] = W[pivrow[i]][colof[j]] : four rows per wave iteration,
     // up to 16 independent gathers in flight per lane
     for (int i0 = wave * 4; i0 < n; i0 += GJB_WAVES * 4) {
@@ -467,7 +541,8 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int i = i0 + rr, j = j0 + jj * 64 + lane;
-                    v[rr][jj] = (i < n && j < n) ? W[(size_t)pivrow[i] * n + colof[j]] : cmake(0.0, 0.0);
+                    v[rr][jj] = cmake(fillv, fillv);
+                    if (i < n && j < n && !dead) v[rr][jj] = W[(size_t)pivrow[i] * n + colof[j]];
                 }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
@@ -480,28 +555,27 @@ __global__ __launch_bounds__(GJB_THREADS) void gj_blocked_kernel(
     }
 }
 
-template <int NB, int CPR, int RPT>
+template <class C>
 size_t gj_smem(int n)
 {
-    using C = GjCfg<NB, CPR, RPT>;
+    constexpr int NB = C::NB, PW = C::PW;
     const size_t rows16 = (size_t)((n + 15) & ~15);
-    return (size_t)NB * rows16 * sizeof(cplx) + NB * sizeof(cplx) + (size_t)C::ROWS * sizeof(cplx) +
-           2 * rows16 * sizeof(int);
+    return (size_t)NB * rows16 * sizeof(cplx) + (size_t)2 * PW * NB * sizeof(cplx) + 2 * rows16 * sizeof(int);
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024 - 1024;      // static __shared__ of the kernel is < 1 KB
 
-template <int NB, int CPR, int RPT>
+template <class C>
 bool gj_fits(int n)
 {
-    return n <= GjCfg<NB, CPR, RPT>::ROWS && gj_smem<NB, CPR, RPT>(n) <= LDS_LIMIT;
+    return n <= C::ROWS && gj_smem<C>(n) <= LDS_LIMIT;
 }
 
-template <int NB, int CPR, int RPT>
+template <class C>
 void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* info)
 {
-    auto kern = gj_blocked_kernel<NB, CPR, RPT>;
-    const size_t smem = gj_smem<NB, CPR, RPT>(n);
+    auto kern = gj_blocked_kernel<C>;
+    const size_t smem = gj_smem<C>(n);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -517,12 +591,12 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
             (void)hipMemset(d_stamps, 0, 64 * 8 * sizeof(unsigned long long));
         }
     }
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(GJB_THREADS), smem, st, n, A, B, stride, info, dbg, d_stamps);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(C::THREADS), smem, st, n, A, B, stride, info, dbg, d_stamps);
     if (d_stamps) {
         (void)hipStreamSynchronize(st);
         unsigned long long h[64 * 8];
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
-        const int np = (n + NB - 1) / NB;
+        const int np = (n + C::NB - 1) / C::NB;
         fprintf(stderr, "[gj stamps] 100 MHz ticks relative to step start; cols: A-in A-out A2-in A2-out panel-done upd-done(P) upd-done(U) B-out\n");
         unsigned long long t0 = h[7];
         for (int sidx = 0; sidx <= np; ++sidx) {
@@ -530,15 +604,29 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %8.2f", h[sidx * 8 + k] ? (double)(h[sidx * 8 + k] - t0) / 100.0 : -1.0);
             fprintf(stderr, "  (us since end of step -1)\n");
         }
+        fprintf(stderr, "[gj stamps] shader clock during the kernel: %.0f MHz (s_memtime / s_memrealtime)\n",
+                (double)(h[403] - h[401]) / ((double)(h[402] - h[400]) / 100.0));
+        fprintf(stderr, "[gj stamps] panel 2, pivot step starts (us):");
+        for (int j = 0; j < 32; ++j) fprintf(stderr, " %.2f", h[300 + j] ? (double)(h[300 + j] - h[300]) / 100.0 : -1.0);
+        fprintf(stderr, "\n[gj stamps] panel 2, step 4 phases (us from step start): winner %.2f  recip+f %.2f  update %.2f  publish %.2f  barrier %.2f\n",
+                (double)(h[340] - h[304]) / 100.0, (double)(h[341] - h[304]) / 100.0, (double)(h[342] - h[304]) / 100.0,
+                (double)(h[343] - h[304]) / 100.0, (double)(h[344] - h[304]) / 100.0);
     }
 }
 
 // which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
+using CfgSplit = GjCfg<32, 2, 1, 8, 12>;   // n <= 256: panel 32, a row split over two lanes, 8 + 4 waves
+using CfgFat = GjCfg<32, 1, 1, 4, 8>;      // n <= 256: panel 32, a whole panel row per lane, 4 + 4 waves
+using CfgMid = GjCfg<16, 1, 1, 8, 12>;     // n <= 512: panel 16, 8 + 4 waves
+
 int gj_pick(int n)
 {
     if (n < 32) return 0;                               // small matrices: the unblocked kernel
-    if (gj_fits<32, 2, 1>(n)) return 1;                 // n <= 256, panel 32, two threads per row
-    if (gj_fits<16, 1, 1>(n)) return 2;                 // n <= 512, panel 16
+    static int fat = -1;
+    if (fat < 0) { const char* e = getenv("NEGF_GJ_CFG"); fat = (e && e[0] == 's') ? 0 : 1; }
+    if (fat && gj_fits<CfgFat>(n)) return 3;
+    if (gj_fits<CfgSplit>(n)) return 1;
+    if (gj_fits<CfgMid>(n)) return 2;
     return 0;
 }
 
@@ -559,22 +647,22 @@ int gj_pick(int n)
 // G[i][j] = W[pivrow[i]][colof[j]].
 // ======================================================================================
 constexpr int WIN = 64;
+constexpr int PW = 8;                              // window kernel: all 8 waves factor the sub-panels
+constexpr int PT = PW * 64;
 
 template <int NBI, int RPT>
 __global__ __launch_bounds__(PT) void gj_window_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride,
     int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw)
 {
-    using C = GjCfg<NBI, 1, RPT>;
+    using C = GjCfg<NBI, 1, RPT, PW, PW>;
     constexpr int S = NBI;
     constexpr int KS = (NBI + 3) / 4;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cplx* rowbuf = reinterpret_cast<cplx*>(smem_raw);            // [NBI]
-    cplx* colbuf = rowbuf + NBI;                                 // [ROWS]
-    cplx* qwin = colbuf + C::ROWS;                               // [NBI][WIN] pivot rows, window columns
-    __shared__ RedSlot red[2][PW];
-    __shared__ cplx piv_ip;
+    cplx* cand = reinterpret_cast<cplx*>(smem_raw);              // [2][PW][NBI] candidate pivot rows
+    cplx* qwin = cand + 2 * PW * NBI;                            // [NBI][WIN] pivot rows, window columns
+    __shared__ u64 slot[3];
     __shared__ int bad_sh;
     __shared__ int team_ctr;
 
@@ -585,6 +673,7 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
     int* colof = pivrow + n;
     int team_expect = 0;
     if (tid == 0) { bad_sh = 0; team_ctr = 0; }
+    if (tid < 3) slot[tid] = 0;
     __syncthreads();
 
     const int fi = lane & 15, fk = lane >> 4;
@@ -607,24 +696,13 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             for (int s = 0; s < S; ++s) a[q][s] = (row_ok && s < kw) ? g[s] : cmake(0.0, 0.0);
         }
         {
-            double bv = -1.0; int bkey = KEY_NONE;
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
-                const int r = tid + q * PT;
-                if (r < n && avail[q]) {
-                    const double v = cabs1(a[q][0]);
-                    const bool take = (v > bv) | ((v == bv) & (r < bkey));
-                    bv = take ? v : bv; bkey = take ? r : bkey;
-                }
-            }
-            wave_argmax(bv, bkey);
-            if (lane == 0) { red[0][wave].v = bv; red[0][wave].key = bkey; }
-        }
-        team_sync(&team_ctr, team_expect, lane);
-        {
-            PanelCtx<NBI, 1, RPT> ctx{a, avail, rowbuf, colbuf, &red[0][0], &piv_ip, &bad_sh, pivrow, colof,
-                                      &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, tid & ~63};
-            PanelSteps<NBI, 1, RPT, 0>::run(ctx);
+            // the slots were left at zero by the previous panel (every column resets the slot two ahead;
+        // the last two columns of a panel publish nothing into theirs)
+        PanelCtx<C> ctx{a, avail, cand, slot, &bad_sh, pivrow, colof,
+                                      &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, nullptr};
+            publish_candidate<C>(ctx, 0, 0, 0);
+            team_sync<PW>(&team_ctr, team_expect, lane);
+            PanelSteps<C, 0>::run(ctx);
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
@@ -770,13 +848,19 @@ __global__ __launch_bounds__(256) void gj_bigupdate_kernel(
 
 __global__ __launch_bounds__(256) void gj_gather_kernel(int n, const cplx* __restrict__ bufA,
                                                          cplx* __restrict__ bufB, size_t mat_stride,
-                                                         const int* __restrict__ piv_all)
+                                                         const int* __restrict__ piv_all,
+                                                         const int* __restrict__ info)
 {
     const cplx* W = bufA + (size_t)blockIdx.y * mat_stride;
     cplx* X = bufB + (size_t)blockIdx.y * mat_stride;
     const int* pivrow = piv_all + (size_t)blockIdx.y * 2 * n;
     const int* colof = pivrow + n;
     const int i = blockIdx.x;
+    if (info[blockIdx.y] != 0) {         // singular / NaN matrix: NaN-filled, bookkeeping not used as an index
+        const double fillv = __builtin_nan("");
+        for (int j = threadIdx.x; j < n; j += 256) X[(size_t)i * n + j] = cmake(fillv, fillv);
+        return;
+    }
     const cplx* srow = W + (size_t)pivrow[i] * n;
     for (int j = threadIdx.x; j < n; j += 256) X[(size_t)i * n + j] = srow[colof[j]];
 }
@@ -791,8 +875,8 @@ __global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __re
 template <int NBI, int RPT>
 void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
 {
-    using C = GjCfg<NBI, 1, RPT>;
-    const size_t smem = (size_t)(NBI + C::ROWS + NBI * WIN) * sizeof(cplx);
+    using C = GjCfg<NBI, 1, RPT, PW, PW>;
+    const size_t smem = (size_t)(2 * PW * NBI + NBI * WIN) * sizeof(cplx);
     auto kern = gj_window_kernel<NBI, RPT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -809,12 +893,13 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
                            (const int*)piv, c0, cw);
     }
     hipLaunchKernelGGL(gj_gather_kernel, dim3(n, nb), dim3(256), 0, st, n, (const cplx*)A, B, stride,
-                       (const int*)piv);
+                       (const int*)piv, (const int*)info);
 }
 
 int gj_large_pick(int n)
 {
-    if (n <= 512 || n < 64) return 0;
+    if (n < 64) return 0;
+    if (n <= PT) return 4;               // <= 512: sub-panel 8, 1 row per thread (only above NEGF_GJ_LARGE_MIN)
     if (n <= PT * 2) return 1;           // <= 1024: sub-panel 8, 2 rows per thread
     if (n <= PT * 4) return 2;           // <= 2048: sub-panel 8, 4 rows per thread
     if (n <= PT * 8) return 3;           // <= 4096: sub-panel 4, 8 rows per thread
@@ -830,15 +915,21 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // Returns true: the result is in B.
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
 {
+    // single-workgroup kernel up to 512 rows unless NEGF_GJ_LARGE_MIN moves the switch-over
+    static int large_min = -1;
+    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 513; }
+    if (n < large_min)
     switch (gj_pick(n)) {
-    case 1: gj_launch<32, 2, 1>(st, n, nb, A, B, stride, info); return true;
-    case 2: gj_launch<16, 1, 1>(st, n, nb, A, B, stride, info); return true;
+    case 1: gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true;
+    case 2: gj_launch<CfgMid>(st, n, nb, A, B, stride, info); return true;
+    case 3: gj_launch<CfgFat>(st, n, nb, A, B, stride, info); return true;
     default: break;
     }
     switch (gj_large_pick(n)) {
     case 1: gj_large_launch<8, 2>(st, n, nb, A, B, stride, piv, info); return true;
     case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info); return true;
     case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info); return true;
+    case 4: gj_large_launch<8, 1>(st, n, nb, A, B, stride, piv, info); return true;
     default: return false;
     }
 }
