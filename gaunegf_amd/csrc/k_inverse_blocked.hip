@@ -1,5 +1,5 @@
 // Blocked Gauss-Jordan inversion with partial pivoting, FP64 MFMA trailing updates and
-// panel LOOK-AHEAD, one workgroup (512 threads, 8 waves) per matrix.   gfx950 / MI355X.
+// panel LOOK-AHEAD, one workgroup (768 threads, 12 waves) per matrix.   gfx950 / MI355X.
 //
 // Replaces G = solve(E S - F - Sigma, I)  (gauNEGF/integrate.py:71, utils.py:52-54,
 // transport.py:154,163,186) for every energy point of the grid.
@@ -15,28 +15,32 @@
 //
 // Block column K = [k0, k0+kw), kw <= NB.  768 threads = 12 waves (<= 168 VGPRs), two teams:
 //   P-team (waves 0-7): PANEL.  The n x kw panel lives in REGISTERS, one row strip (16
-//      complex128) per thread.  kw unblocked Gauss-Jordan column steps with partial
-//      pivoting (|re|+|im| as LAPACK izamax; among not-yet-used rows) run on the strips;
-//      only the pivot row, the pivot column and the per-wave arg-max partials go through
-//      LDS; the search for column j+1 is fused into the update of column j, the wave
-//      arg-max uses DPP lane moves, waves that do not hold the pivot row run a
-//      select-free update.  The phase is a latency chain (two team barriers per column),
-//      so it runs CONCURRENTLY with the update of the previous block column:
+//      complex128) per lane; the two strips of a panel row sit in the same wave (lanes l and
+//      l+32).  kw unblocked Gauss-Jordan column steps with partial pivoting (|re|+|im| as
+//      LAPACK izamax; among not-yet-used rows) run on the strips with ONE team barrier per
+//      column: after updating its strips for column j every wave finds its best candidate
+//      for column j+1 (DPP max of a packed 64-bit key), publishes that candidate's whole,
+//      already updated panel row to LDS and merges the key with an LDS atomic max; after the
+//      barrier every lane reads the winning key and the winner's row.  The team barrier is an
+//      LDS counter (gfx950 has one hardware barrier per workgroup) without fences: DS
+//      instructions of a wave execute in order.  The phase is a latency chain, so it runs
+//      CONCURRENTLY with the update of the previous block column:
 //   U-team (waves 8-11, joined by the P-team once its panel is done: the update items come
 //      from a shared LDS work queue): TRAILING UPDATE of step k on the matrix cores, in place:
 //         W[i][J] = (i pivot row of panel k ? 0 : W[i][J]) + P_k[i][:] * Q_k[:][J]
 //      with P_k in LDS (k-major, conflict-free A-operand reads), the Q_k fragments of a
-//      column tile in registers, C tiles prefetched; a 16x16 complex tile = 4 real
-//      v_mfma_f64_16x16x4_f64 chains per 4-deep k-step
+//      column tile in registers, the next C tile in flight during the MFMAs, no divergent
+//      branch in the loop (clamped loads + selects, pivot rows from a bit mask); a 16x16
+//      complex tile = 4 real v_mfma_f64_16x16x4_f64 chains per 4-deep k-step
 //      (Cr += Pr Qr; Cr += Pi (-Qi); Ci += Pr Qi; Ci += Pi Qr).
-//   Look-ahead: at step k the P-team first applies step k to the columns of panel k+1
-//      (a few tiles), then factors panel k+1 in registers while the U-team updates all
-//      other columns.  The teams meet at a workgroup barrier; the strips of panel k+1
+//   Look-ahead: at step k all waves first apply step k to the columns of panel k+1
+//      (a few tiles), then the P-team factors panel k+1 in registers while the U-team updates
+//      all other columns.  The teams meet at a workgroup barrier; the columns of panel k+1
 //      then become P_{k+1} in LDS and the pivot rows are snapshotted as Q_{k+1}.
-//      Team barriers are LDS counters (gfx950 has one hardware barrier per workgroup).
 // Flops: 8 n^3 per matrix (complex MAC = 8) -- the LU + triangular-inversion optimum.
-// Ties in the pivot search are broken by the lower physical row index (LAPACK: lower
-// logical index); this only matters for exactly equal |.|_1 values.
+// Pivot candidates are compared on the upper 36 mantissa bits of |.|_1; ties go to the lower
+// physical row index (LAPACK: lower logical index).  A singular or NaN matrix is reported through
+// info (1-based column) and its result is NaN-filled.
 //
 // Data layout: row-major complex128 (interleaved), ld = n.  A lane fetches one
 // complex element (16 B) per MFMA operand; 16 lanes cover 256 contiguous bytes of
@@ -70,8 +74,10 @@ __device__ __forceinline__ void team_sync(int* ctr, int& expect, int lane)
 {
     asm volatile("" ::: "memory");
     expect += PW;
-    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) { }
+    if (lane == 0) {                     // one lane polls: the LDS sees 4-byte reads, not 64 x 4
+        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < expect) { }
+    }
     asm volatile("" ::: "memory");
 }
 
@@ -250,11 +256,13 @@ struct PanelSteps {
                 x.avail[q] = x.avail[q] && !is_piv;
             }
             if constexpr (J == 4) pstamp(x, 342);
+            if constexpr (J == 4) { if (x.st && x.lane == 0) { x.st[360 + x.wave] = __builtin_amdgcn_s_memrealtime(); x.st[370 + x.wave] = wave_has_piv; } }
             // (5) candidates for column J+1 from the freshly updated strips
             if constexpr (J + 1 < NB) {
                 if (J + 1 < x.kw) publish_candidate<C>(x, J + 1, (J + 1) / S, (J + 1) % S);
             }
             if constexpr (J == 4) pstamp(x, 343);
+            if constexpr (J == 4) { if (x.st && x.lane == 0) x.st[350 + x.wave] = __builtin_amdgcn_s_memrealtime(); }
             team_sync<PW>(x.team_ctr, x.team_expect, x.lane);
             if constexpr (J == 4) pstamp(x, 344);
             // last column of the panel: every wave has read its slot by now; leave all three zero
@@ -326,8 +334,7 @@ __device__ __forceinline__ void gj_update_item(const cplx* __restrict__ Pt, int 
 template <class C>
 __global__ __launch_bounds__(C::THREADS) void gj_blocked_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride, int* __restrict__ info,
-    int dbg /* ablation switches, 0 in production: 2 = no MFMA, 4 = no tile loads, 16 = U-team idle,
-               32 = no pivot steps */,
+    int dbg /* ablation switches, 0 in production: 16 = U-team idle, 32 = no pivot steps */,
     unsigned long long* __restrict__ stamps /* diagnostic build only (NEGF_GJ_STAMPS): wall-clock
                stamps of workgroup 0, [step+1][8]; nullptr in production */)
 {
@@ -513,8 +520,12 @@ __global__ __launch_bounds__(C::THREADS) void gj_blocked_kernel(
                 const int c_lo = tj * 16, c_hi = min(n, c_lo + 16);
                 if (c_lo >= k0 && c_hi <= k0 + kw) continue;                         // inside block column s
                 if (has_next && c_lo >= n0 && c_hi <= n0 + nw) continue;             // done in the look-ahead
-                gj_update_item<KS>(Pt, rows16, W, X, rowmask, n, k0, kw, tj, part ? rhalf : 0, part ? tiles : rhalf,
-                                   has_next ? n0 : 0, has_next ? n0 + nw : 0, false, lane);
+                const int r0 = part ? rhalf : 0, r1 = part ? tiles : rhalf;
+                const int lo = has_next ? n0 : 0, hi = has_next ? n0 + nw : 0;
+                // a narrow last panel runs fewer k-steps
+                if (KS > 4 && kw <= 8) gj_update_item<2>(Pt, rows16, W, X, rowmask, n, k0, kw, tj, r0, r1, lo, hi, false, lane);
+                else if (KS > 4 && kw <= 16) gj_update_item<4>(Pt, rows16, W, X, rowmask, n, k0, kw, tj, r0, r1, lo, hi, false, lane);
+                else gj_update_item<KS>(Pt, rows16, W, X, rowmask, n, k0, kw, tj, r0, r1, lo, hi, false, lane);
             }
         }
         stamp(step, 5, 0);
@@ -604,6 +615,11 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %8.2f", h[sidx * 8 + k] ? (double)(h[sidx * 8 + k] - t0) / 100.0 : -1.0);
             fprintf(stderr, "  (us since end of step -1)\n");
         }
+        fprintf(stderr, "[gj stamps] panel 2, step 4 per wave (us from step start; * = wave holding the pivot row): update done");
+        for (int w = 0; w < C::PW; ++w) fprintf(stderr, " %.2f%s", (double)(h[360 + w] - h[304]) / 100.0, h[370 + w] ? "*" : "");
+        fprintf(stderr, " | barrier arrival");
+        for (int w = 0; w < C::PW; ++w) fprintf(stderr, " %.2f", (double)(h[350 + w] - h[304]) / 100.0);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[gj stamps] shader clock during the kernel: %.0f MHz (s_memtime / s_memrealtime)\n",
                 (double)(h[403] - h[401]) / ((double)(h[402] - h[400]) / 100.0));
         fprintf(stderr, "[gj stamps] panel 2, pivot step starts (us):");
@@ -616,15 +632,11 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
 
 // which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
 using CfgSplit = GjCfg<32, 2, 1, 8, 12>;   // n <= 256: panel 32, a row split over two lanes, 8 + 4 waves
-using CfgFat = GjCfg<32, 1, 1, 4, 8>;      // n <= 256: panel 32, a whole panel row per lane, 4 + 4 waves
 using CfgMid = GjCfg<16, 1, 1, 8, 12>;     // n <= 512: panel 16, 8 + 4 waves
 
 int gj_pick(int n)
 {
     if (n < 32) return 0;                               // small matrices: the unblocked kernel
-    static int fat = -1;
-    if (fat < 0) { const char* e = getenv("NEGF_GJ_CFG"); fat = (e && e[0] == 's') ? 0 : 1; }
-    if (fat && gj_fits<CfgFat>(n)) return 3;
     if (gj_fits<CfgSplit>(n)) return 1;
     if (gj_fits<CfgMid>(n)) return 2;
     return 0;
@@ -922,7 +934,6 @@ bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, siz
     switch (gj_pick(n)) {
     case 1: gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true;
     case 2: gj_launch<CfgMid>(st, n, nb, A, B, stride, info); return true;
-    case 3: gj_launch<CfgFat>(st, n, nb, A, B, stride, info); return true;
     default: break;
     }
     switch (gj_large_pick(n)) {
