@@ -927,9 +927,11 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // Returns true: the result is in B.
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
 {
-    // single-workgroup kernel up to 512 rows unless NEGF_GJ_LARGE_MIN moves the switch-over
+    // single-workgroup kernel below 384 rows (measured cross-over with the windowed path on
+    // MI355X: 300 -> 17.7 vs 24.4 ms, 400 -> 38.5 vs 34.8 ms per 1000 matrices); NEGF_GJ_LARGE_MIN
+    // moves the switch-over
     static int large_min = -1;
-    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 513; }
+    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 384; }
     if (n < large_min)
     switch (gj_pick(n)) {
     case 1: gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true;

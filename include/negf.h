@@ -16,8 +16,10 @@
  *   - the caller owns every buffer; nothing is retained after a call returns,
  *     except data copied by negf_set_system / negf_sigma_* into the context.
  *   - return 0 = ok, <0 = argument / runtime error, >0 = numerical condition
- *     (NEGF_ESINGULAR: at least one energy hit an exactly zero pivot; info[k]
- *     holds the 1-based pivot column for energy k, LAPACK style).  A self-energy
+ *     (NEGF_ESINGULAR: at least one energy hit an exactly zero pivot or a NaN
+ *     column; info[k] holds the 1-based pivot column for energy k, LAPACK style,
+ *     and G(E_k) is NaN-filled by the blocked kernels -- numpy/jax solve would
+ *     return inf/NaN there as well; the other energies are unaffected).  A self-energy
  *     fixed point that stops at its iteration cap is NOT an error (the reference
  *     stops silently too, surfG1D.py:290-293); it is reported via converged[].
  *   - one negf_ctx per (process, GPU); calls are blocking unless noted and the

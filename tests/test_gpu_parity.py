@@ -46,10 +46,10 @@ def test_library_is_loaded_in_process():
 
 
 @pytest.mark.parametrize("N,algo", [(n, a) for n in (1, 3, 17, 32, 40, 64, 100, 200, 256) for a in (1, 2)] +
-                         [(n, 2) for n in (257, 300, 500, 512, 513, 600, 1030)])
+                         [(n, 2) for n in (257, 300, 383, 384, 500, 512, 513, 600, 1030)])
 def test_G_of_E_per_energy(engine, N, algo):
     """G(E) = solve(E S - F - Sigma, I) for every energy: unblocked kernel (algo 1), blocked
-    MFMA kernels (algo 2: panel 32 up to n=256, panel 16 up to 512, two-level above)."""
+    MFMA kernels (algo 2: panel 32 up to n=256, panel 16 up to 383, two-level windowed above)."""
     from gaunegf_amd.integrate import GrBatch
     F, S, g_dev, g_ref = _const_provider(N, 100 + N)
     E = np.concatenate([np.linspace(-3, 3, 9), np.array([0.3 + 0.5j, -1.2 + 2j, 0.05 + 1e-3j])])
@@ -135,6 +135,35 @@ def test_singular_matrix_is_reported(engine):
         GrInt(F, S, Zero(), np.array([0.0, 1.0]), np.array([1.0, 1.0]))     # E=0: A == 0 exactly
     assert any("singular" in str(r.message) for r in rec)
     assert engine.last_info[0] == 1 and engine.last_info[1] == 0
+
+
+@pytest.mark.parametrize("N", [64, 200, 300, 400])
+def test_singular_and_nan_matrices_in_blocked_kernels(engine, N):
+    """An exactly singular matrix (E S - F - Sigma == 0) and a NaN matrix in the middle of a batch:
+    reported through info, NaN-filled, and the neighbouring energies are untouched."""
+    from gaunegf_amd.integrate import GrBatch
+
+    class Probe:                          # duck-typed provider (integrate.py:169): Sigma = 0 or NaN
+        def __init__(self, bad): self.bad = bad
+        def sigmaTot(self, E):
+            z = np.zeros((N, N), dtype=complex)
+            if self.bad == "nan" and abs(E - 1.0) < 1e-12:
+                z[:, 3] = np.nan
+            return z
+        def sigma(self, E, i): return np.zeros((N, N), dtype=complex)
+
+    S = np.eye(N)
+    Fz, _ = random_system(N, 7)
+    E = np.array([0.5 + 0.1j, 1.0 + 0j, 2.0 + 0.1j])
+    for bad, F in (("singular", np.eye(N)), ("nan", Fz)):     # E=1: 1*I - I == 0
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            G = GrBatch(F, S, Probe(bad), E)
+        assert np.all(np.isnan(G[1])), bad
+        assert engine.last_info[1] != 0 and engine.last_info[0] == 0 and engine.last_info[2] == 0
+        for k in (0, 2):
+            ref = np.linalg.inv(E[k] * S - F)
+            assert rel_fro(G[k], ref) < TOL, (bad, k)
 
 
 def test_transmission_and_dos_golden(engine, golden_num):
