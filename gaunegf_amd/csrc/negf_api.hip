@@ -103,11 +103,15 @@ void free_mbuffers(negf_ctx* c)
 int auto_batch(negf_ctx* c, int m)
 {
     if (c->batch_user > 0) return std::min(c->batch_user, std::max(m, 1));
-    // three n x n complex128 work matrices per in-flight energy; keep the working
-    // set within ~6 GB (a sliver of the 288 GB of HBM3E, enough to fill 256 CUs
-    // several times over) and never above the grid length
+    // three n x n complex128 work matrices per in-flight energy.  The working set may take a
+    // quarter of the free HBM (288 GB per MI355X), at most 64 GB: large matrices need hundreds of
+    // energies in flight so that the one-workgroup-per-matrix panel kernels cover the 256 CUs
+    // (n = 2000: 192 MB per energy -> 333 in flight); never above the grid length.
     const double per = 3.0 * 16.0 * (double)c->n * (double)c->n;
-    long b = (long)(6.0e9 / std::max(per, 1.0));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)24e9;
+    const double budget = std::min(64.0e9, std::max(2.0e9, 0.25 * (double)free_b));
+    long b = (long)(budget / std::max(per, 1.0));
     b = std::max(1L, std::min(b, 4096L));
     return (int)std::min<long>(b, std::max(m, 1));
 }
