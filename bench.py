@@ -142,10 +142,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    # NEGF_BENCH_REHEARSAL=1: several ranks share the visible GPUs and talk over gloo -- a dry run
+    # of the N > 1 control flow on a one-GPU box (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("NEGF_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from gaunegf_amd.engine import Engine
     from gaunegf_amd.matTools import formSigma
@@ -238,7 +246,7 @@ def main():
                          "flops_per_point": flops_per_launch_pt,
                          "other_ms_per_step": {"assemble": asm_ms / args.steps, "accumulate": acc_ms / args.steps}},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:           # the CPU leg is an N=1 figure (rank 0 only)
             line["cpu_baseline"] = cpu_baseline(F, S, inds, np.real(E_loc), np.real(w_loc))
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         if args.extra:
