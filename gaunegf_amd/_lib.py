@@ -60,6 +60,7 @@ SIGNATURES = {
     "negf_profile_reset": (C.c_int, [_vp]),
     "negf_profile_read": (C.c_int, [_vp, C.c_char_p, _dp, _ip]),
     "negf_set_inverse_algo": (C.c_int, [_vp, C.c_int]),
+    "negf_set_gamma_algo": (C.c_int, [_vp, C.c_int]),
     "negf_selftest_mfma": (C.c_int, [_vp, _dp]),
 }
 

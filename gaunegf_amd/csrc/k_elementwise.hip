@@ -130,6 +130,71 @@ void launch_gamma_dense(hipStream_t st, int n, int nb, const cplx* sig, size_t s
     hipLaunchKernelGGL(gamma_kernel, dim3(gx, nb), dim3(EW_THREADS), 0, st, n, sig, stride_sig, gam);
 }
 
+// -------------------------------------------------------------- compact Gamma
+// The coupling matrices of block-structured self-energies vanish outside the contact orbitals:
+//     Gamma = scatter of a small K x K matrix over an index list idx[0..K).
+// G Gamma G^H and Tr[Gamma_L G Gamma_R G^H] then only need the columns / the block of G on those
+// indices (integrate.py:74-82 and transport.py:150-163 multiply the dense n x n matrices).
+//
+// small Gamma of the contacts [c0, c1): block diagonal, block c at its position in the
+// concatenated index list, i (B - B^H) of the contact block B (stride 0: constant blocks).
+__global__ __launch_bounds__(EW_THREADS) void gamma_small_kernel(
+    int K, int c0, int c1, const int* __restrict__ d_nc, const int* __restrict__ d_blk_off,
+    const int* __restrict__ d_inds_off, const cplx* __restrict__ blk, size_t blk_stride,
+    cplx* __restrict__ out, size_t out_stride)
+{
+    const int b = blockIdx.y;
+    const cplx* B = blk + (size_t)b * blk_stride;
+    cplx* O = out + (size_t)b * out_stride;
+    const int base = d_inds_off[c0];
+    for (int t = blockIdx.x * EW_THREADS + threadIdx.x; t < K * K; t += gridDim.x * EW_THREADS) {
+        const int a = t / K, e = t - a * K;
+        cplx v = cmake(0.0, 0.0);
+        for (int c = c0; c < c1; ++c) {
+            const int o = d_inds_off[c] - base, k = d_nc[c];
+            if (a >= o && a < o + k && e >= o && e < o + k) {
+                const cplx x = B[d_blk_off[c] + (a - o) * k + (e - o)];
+                const cplx y = B[d_blk_off[c] + (e - o) * k + (a - o)];
+                // i (x - conj(y))
+                v = cmake(-(x.y + y.y), x.x - y.x);
+            }
+        }
+        O[t] = v;
+    }
+}
+
+void launch_gamma_small(hipStream_t st, int K, int c0, int c1, int nb, const int* d_nc, const int* d_blk_off,
+                        const int* d_inds_off, const cplx* blk, size_t blk_stride, cplx* out, size_t out_stride)
+{
+    int gx = (K * K + EW_THREADS - 1) / EW_THREADS;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(gamma_small_kernel, dim3(gx, nb), dim3(EW_THREADS), 0, st, K, c0, c1, d_nc, d_blk_off,
+                       d_inds_off, blk, blk_stride, out, out_stride);
+}
+
+// out[b][a][e] = G[b][ridx ? ridx[a] : a][cidx[e]]     (nr x nc, leading dimension nc)
+__global__ __launch_bounds__(EW_THREADS) void gather_block_kernel(
+    int n, int nr, int nc, const cplx* __restrict__ G, size_t strideG, const int* __restrict__ ridx,
+    const int* __restrict__ cidx, cplx* __restrict__ out, size_t out_stride)
+{
+    const int b = blockIdx.y;
+    const cplx* Gb = G + (size_t)b * strideG;
+    cplx* O = out + (size_t)b * out_stride;
+    for (int t = blockIdx.x * EW_THREADS + threadIdx.x; t < nr * nc; t += gridDim.x * EW_THREADS) {
+        const int a = t / nc, e = t - a * nc;
+        O[t] = Gb[(size_t)(ridx ? ridx[a] : a) * n + cidx[e]];
+    }
+}
+
+void launch_gather_block(hipStream_t st, int n, int nr, int nc, int nb, const cplx* G, size_t strideG,
+                         const int* ridx, const int* cidx, cplx* out, size_t out_stride)
+{
+    int gx = (nr * nc + EW_THREADS - 1) / EW_THREADS;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gather_block_kernel, dim3(gx, nb), dim3(EW_THREADS), 0, st, n, nr, nc, G, strideG, ridx,
+                       cidx, out, out_stride);
+}
+
 // -------------------------------------------------------------- accumulate
 // acc[i] += sum_b w[b] * X[b][i] in a FIXED order (bitwise reproducible from run to run):
 // the batch is cut into chunks of ACC_CHUNK energies; pass 1 reduces each chunk into

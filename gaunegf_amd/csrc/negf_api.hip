@@ -75,7 +75,7 @@ int download(negf_ctx* c, T* dst, const T* src, size_t count)
 void free_provider(SigmaProvider* p)
 {
     if (!p) return;
-    dev_free(p->d_const_c); dev_free(p->d_const_tot); dev_free(p->d_hbase);
+    dev_free(p->d_const_c); dev_free(p->d_const_tot); dev_free(p->d_hbase); dev_free(p->d_const_blk);
     dev_free(p->d_inds); dev_free(p->d_nc); dev_free(p->d_blk_off); dev_free(p->d_inds_off);
     dev_free(p->d_n_atoms); dev_free(p->d_atom_off);
     dev_free(p->d_alpha); dev_free(p->d_Salpha); dev_free(p->d_beta); dev_free(p->d_Sbeta);
@@ -89,8 +89,8 @@ void free_provider(SigmaProvider* p)
 void free_workspace(negf_ctx* c)
 {
     dev_free(c->d_A); dev_free(c->d_T1); dev_free(c->d_T2); dev_free(c->d_blk);
-    dev_free(c->d_ipiv); dev_free(c->d_site); dev_free(c->d_scratch);
-    c->batch = 0; c->blk_cap = 0; c->scratch_cap = 0;
+    dev_free(c->d_ipiv); dev_free(c->d_site); dev_free(c->d_scratch); dev_free(c->d_gsmall);
+    c->batch = 0; c->blk_cap = 0; c->scratch_cap = 0; c->gsmall_cap = 0;
 }
 
 void free_mbuffers(negf_ctx* c)
@@ -322,6 +322,48 @@ int run_gamma(negf_ctx* c, SigmaProvider* p, int contact /* -1 total */, int m0,
     return NEGF_EINVAL;
 }
 
+// ---- compact coupling matrices (see k_elementwise.hip): usable when Gamma_c is confined to the
+// contact's index list and all lists together cover at most half of the orbitals
+bool compact_available(const negf_ctx* c, const SigmaProvider* p)
+{
+    if (c->gamma_algo == 1) return false;
+    if (p->kind == SK_CONST) return p->compact_ok;
+    if ((p->kind == SK_CHAIN1D || p->kind == SK_BETHE) && !p->d_xi) {
+        int tot = 0;
+        for (int k : p->nc) tot += k;
+        return 2 * tot <= c->n;
+    }
+    return false;
+}
+
+struct GammaSmall { const cplx* mat; size_t stride; const int* idx; int K; };
+
+// small Gamma of `contact` (or of all contacts, block diagonal, for contact < 0) for the batch
+// [m0, m0+nb) into slot `slot` (0/1) of c->d_gsmall
+int run_gamma_small(negf_ctx* c, SigmaProvider* p, int contact, int nb, int slot, GammaSmall* g)
+{
+    const int c0 = contact < 0 ? 0 : contact, c1 = contact < 0 ? p->n_contacts : contact + 1;
+    int K = 0;
+    for (int k = c0; k < c1; ++k) K += p->nc[k];
+    int Kmax = 0;
+    for (int k : p->nc) Kmax += k;
+    const size_t need = (size_t)2 * nb * Kmax * Kmax;
+    if (need > c->gsmall_cap) {
+        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+        dev_free(c->d_gsmall); c->gsmall_cap = 0;
+        int rc = dev_alloc(&c->d_gsmall, need);
+        if (rc) return rc;
+        c->gsmall_cap = need;
+    }
+    cplx* out = c->d_gsmall + (size_t)slot * nb * Kmax * Kmax;
+    const bool constant = p->kind == SK_CONST;
+    launch_gamma_small(c->stream, K, c0, c1, constant ? 1 : nb, p->d_nc, p->d_blk_off, p->d_inds_off,
+                       constant ? p->d_const_blk : c->d_blk, constant ? 0 : (size_t)p->blk_stride, out,
+                       (size_t)K * K);
+    g->mat = out; g->stride = constant ? 0 : (size_t)K * K; g->idx = p->d_inds + p->inds_off[c0]; g->K = K;
+    return NEGF_OK;
+}
+
 int check_ready(negf_ctx* c, SigmaProvider* p, int m)
 {
     if (!c || c->n <= 0) return NEGF_ESTATE;
@@ -421,6 +463,13 @@ int negf_set_inverse_algo(negf_ctx* c, int algo)
     return NEGF_OK;
 }
 
+int negf_set_gamma_algo(negf_ctx* c, int algo)
+{
+    if (!c || algo < 0 || algo > 1) return NEGF_EINVAL;
+    c->gamma_algo = algo;
+    return NEGF_OK;
+}
+
 int negf_set_system(negf_ctx* c, int n, const double* F, const double* S)
 {
     if (!c || n <= 0 || !F || !S) return NEGF_EINVAL;
@@ -456,6 +505,8 @@ int negf_set_system(negf_ctx* c, int n, const double* F, const double* S)
 }
 
 // ------------------------------------------------------------------ providers
+static int setup_blocks(negf_ctx* c, SigmaProvider* p, int n_contacts, const int* nc, const int* inds);
+
 int negf_sigma_const(negf_ctx* c, int n_contacts, const double* sigma, int* handle)
 {
     if (!c || c->n <= 0) return NEGF_ESTATE;
@@ -477,6 +528,39 @@ int negf_sigma_const(negf_ctx* c, int n_contacts, const double* sigma, int* hand
     for (size_t i = 0; i < n2; ++i) hb[i] = cadd(Fh[i], tot[i]);
     if ((rc = upload(c, p->d_const_c, s, n2 * n_contacts)) || (rc = upload(c, p->d_const_tot, tot.data(), n2)) ||
         (rc = upload(c, p->d_hbase, hb.data(), n2))) { free_provider(p); return rc; }
+    // support of each contact matrix (rows or columns holding a nonzero): formSigma-style contacts
+    // (matTools.py:90-120) only touch their own orbitals, so Gamma_c is a small block
+    {
+        const int n = c->n;
+        std::vector<int> ks(n_contacts), inds;
+        for (int k = 0; k < n_contacts; ++k) {
+            const cplx* m = s + (size_t)k * n2;
+            std::vector<char> used(n, 0);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j)
+                    if (m[(size_t)i * n + j].x != 0.0 || m[(size_t)i * n + j].y != 0.0) { used[i] = 1; used[j] = 1; }
+            int cnt = 0;
+            for (int i = 0; i < n; ++i) if (used[i]) { inds.push_back(i); ++cnt; }
+            ks[k] = cnt;
+        }
+        bool ok = 2 * (int)inds.size() <= n;
+        for (int k : ks) ok = ok && k > 0;
+        if (ok) {
+            if ((rc = setup_blocks(c, p, n_contacts, ks.data(), inds.data()))) { free_provider(p); return rc; }
+            std::vector<cplx> blk((size_t)p->blk_stride);
+            for (int k = 0; k < n_contacts; ++k) {
+                const cplx* m = s + (size_t)k * n2;
+                const int* id = p->h_inds.data() + p->inds_off[k];
+                for (int a = 0; a < ks[k]; ++a)
+                    for (int e = 0; e < ks[k]; ++e)
+                        blk[(size_t)p->blk_off[k] + (size_t)a * ks[k] + e] = m[(size_t)id[a] * n + id[e]];
+            }
+            if ((rc = dev_alloc(&p->d_const_blk, blk.size())) || (rc = upload(c, p->d_const_blk, blk.data(), blk.size()))) {
+                free_provider(p); return rc;
+            }
+            p->compact_ok = true;
+        }
+    }
     *handle = add_provider(c, p);
     return NEGF_OK;
 }
@@ -672,6 +756,22 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
+        if (compact_available(c, p)) {
+            // G Gamma G^H = (G[:, I] Gamma_II) G[:, I]^H : Gc and X live in the free buffer W2
+            GammaSmall g;
+            { ProfScope ps(c, "gamma"); if ((rc = run_gamma_small(c, p, contact, nb, 0, &g))) return rc; }
+            cplx* Gc = c->W2;                              // [nb][n x K]
+            cplx* X = c->W2 + (size_t)n * g.K;             // [nb][n x K]   (2 n K <= n^2)
+            {
+                ProfScope ps(c, "zgemm");
+                launch_gather_block(c->stream, n, n, g.K, nb, c->G, n2, nullptr, g.idx, Gc, n2);
+                launch_zgemm(c->stream, n, g.K, g.K, nb, Gc, g.K, n2, g.mat, g.K, g.stride, 0, X, g.K, n2);
+                launch_zgemm(c->stream, n, n, g.K, nb, X, g.K, n2, Gc, g.K, n2, 1, c->W1, n, n2);
+            }
+            ProfScope ps(c, "accumulate");
+            launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);
+            continue;
+        }
         size_t gs = 0;
         const cplx* gam = nullptr;
         { ProfScope ps(c, "gamma"); if ((rc = run_gamma(c, p, contact, m0, nb, c->W1, c->W2, &gam, &gs))) return rc; }
@@ -715,6 +815,26 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
         const int nb = std::min(half, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
         run_inverse(c, nb, c->d_info + m0);
+        if (spin_mode == NEGF_SPIN_RESTRICTED && compact_available(c, p)) {
+            // T = Re sum_ij Y_ij conj(G_ij), Y = Gamma_L G Gamma_R: only G[I_L, I_R] enters
+            GammaSmall gL, gR;
+            {
+                ProfScope ps(c, "gamma");
+                if ((rc = run_gamma_small(c, p, cL, nb, 0, &gL))) return rc;
+                if ((rc = run_gamma_small(c, p, cR, nb, 1, &gR))) return rc;
+            }
+            const size_t kk = (size_t)gL.K * gR.K;            // 3 kk <= n^2
+            cplx* Glr = c->W2; cplx* Xs = c->W2 + kk; cplx* Ys = c->W2 + 2 * kk;
+            {
+                ProfScope ps(c, "zgemm");
+                launch_gather_block(c->stream, n, gL.K, gR.K, nb, c->G, n2, gL.idx, gR.idx, Glr, n2);
+                launch_zgemm(c->stream, gL.K, gR.K, gL.K, nb, gL.mat, gL.K, gL.stride, Glr, gR.K, n2, 0, Xs, gR.K, n2);
+                launch_zgemm(c->stream, gL.K, gR.K, gR.K, nb, Xs, gR.K, n2, gR.mat, gR.K, gR.stride, 0, Ys, gR.K, n2);
+            }
+            ProfScope ps(c, "trace");
+            launch_trace_dot(c->stream, gL.K, gR.K, nb, Ys, gR.K, n2, Glr, gR.K, n2, T_dev + m0, 1);
+            continue;
+        }
         cplx* G = c->G;
         const cplx* gamL = nullptr;           // [nb] (or one shared matrix)
         const cplx* gamR = nullptr;

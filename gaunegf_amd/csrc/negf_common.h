@@ -96,6 +96,10 @@ struct SigmaProvider {
     double* d_Slist = nullptr;     // [n_contacts][12][81]
     double* d_Vlist = nullptr;
     cplx* d_xi = nullptr;          // [n*n] or null
+    // compact coupling matrices: Gamma_c lives on the index list inds[inds_off[c] .. +nc[c]) only
+    // (block providers without Xi; CONST providers whose matrices vanish outside a small support)
+    bool compact_ok = false;
+    cplx* d_const_blk = nullptr;   // CONST: Sigma_c restricted to its support, [blk_stride]
     // PRECOMPUTED
     int m_pre = 0;
     int pre_nc = 0;
@@ -137,6 +141,9 @@ struct negf_ctx {
     double* d_scal = nullptr;      // [m_cap][8] scalar outputs
     double* d_site = nullptr;      // [batch][n] per-site DOS staging
     int inverse_algo = 0;
+    int gamma_algo = 0;            // 0: compact Gamma products when the provider allows, 1: always dense
+    cplx* d_gsmall = nullptr;      // small Gamma matrices of a batch (compact path)
+    size_t gsmall_cap = 0;
     int last_m = 0;
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -196,6 +203,10 @@ void launch_dos(hipStream_t st, int n, int nb, const cplx* G, double* dos_tot, d
 
 // Gamma = i (Sigma - Sigma^H) for nb dense matrices (stride 0 allowed on input)
 void launch_gamma_dense(hipStream_t st, int n, int nb, const cplx* sig, size_t stride_sig, cplx* gam);
+void launch_gamma_small(hipStream_t st, int K, int c0, int c1, int nb, const int* d_nc, const int* d_blk_off,
+                        const int* d_inds_off, const cplx* blk, size_t blk_stride, cplx* out, size_t out_stride);
+void launch_gather_block(hipStream_t st, int n, int nr, int nc, int nb, const cplx* G, size_t strideG,
+                         const int* ridx, const int* cidx, cplx* out, size_t out_stride);
 
 // dense Sigma from contact blocks: out[b] = scatter-add of selected contacts (contact<0: all)
 void launch_scatter_blocks(hipStream_t st, int n, int nb, const cplx* blk, int blk_stride,

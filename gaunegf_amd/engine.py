@@ -79,6 +79,10 @@ class Engine:
     def set_inverse_algo(self, algo):
         check(self._lib.negf_set_inverse_algo(self._ctx, int(algo)), "negf_set_inverse_algo")
 
+    def set_gamma_algo(self, algo):
+        """0: compact Gamma products where the provider allows (default), 1: dense n x n products."""
+        check(self._lib.negf_set_gamma_algo(self._ctx, int(algo)), "negf_set_gamma_algo")
+
     def sync(self):
         check(self._lib.negf_sync(self._ctx), "negf_sync")
 

@@ -191,6 +191,12 @@ int negf_profile_read(negf_ctx* ctx, const char* family, double* total_ms, int* 
 /* choose the inverse kernel: 0 = auto, 1 = unblocked Gauss-Jordan (any n),
  * 2 = blocked Gauss-Jordan with FP64 MFMA trailing updates */
 int negf_set_inverse_algo(negf_ctx* ctx, int algo);
+/* G Gamma G^H (integrate.py:81) and Tr[Gamma_L G Gamma_R G^H] (transport.py:156-157):
+ * 0 = auto -- when the coupling matrices only touch the contact orbitals (CONST providers
+ * with a small support, CHAIN1D / BETHE blocks without an orthogonalisation matrix) the
+ * products run on the columns / the block of G on those orbitals only (same sums, the
+ * terms that are exactly zero are skipped); 1 = always the dense n x n products */
+int negf_set_gamma_algo(negf_ctx* ctx, int algo);
 /* run the FP64 MFMA fragment-layout probe; max abs error vs an exact integer
  * product (0.0 expected) */
 int negf_selftest_mfma(negf_ctx* ctx, double* max_err);

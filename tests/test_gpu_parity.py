@@ -310,6 +310,46 @@ def _chain_system(N, nc, seed, eta):
     return F, S, g_dev, g_ref
 
 
+def test_compact_gamma_products_match_dense_and_oracle(engine):
+    """G Gamma G^H and Tr[Gamma_L G Gamma_R G^H] through the contact columns / block of G only
+    (negf_set_gamma_algo 0) against the dense n x n products (1) and the oracle, for a constant
+    provider (support detected from the matrices) and a 1-D chain provider (contact blocks)."""
+    from gaunegf_amd.integrate import GrLessInt
+    from gaunegf_amd.transport import _transmission_kernel_restricted
+    N, nc = 96, 12
+    E = np.linspace(-2, 2, 24); w = np.full(24, 4.0 / 24) + 0j
+    F, S, g_dev, g_ref = _const_provider(N, 321)
+    Fc, Sc, gc_dev, gc_ref = _chain_system(N, nc, 77, 1e-3)
+    gc_dev.force_iters = 25; gc_ref.force_iters = 25
+    for (f, s, gd, gr) in ((F, S, g_dev, g_ref), (Fc, Sc, gc_dev, gc_ref)):
+        for ind in (None, 0, -1):
+            res = {}
+            for algo in (0, 1):
+                engine.set_gamma_algo(algo)
+                try:
+                    res[algo] = GrLessInt(f, s, gd, E, w, ind)
+                finally:
+                    engine.set_gamma_algo(0)
+            ref = oracle.GrLessInt(f, s, gr, E, w, ind)
+            assert rel_fro(res[0], res[1]) < 1e-12, ind
+            assert rel_fro(res[0], ref) < TOL and rel_fro(res[1], ref) < TOL, ind
+        h = gd._negf_lower(engine)
+        engine.set_system(f, s)
+        T = {}
+        for algo in (0, 1):
+            engine.set_gamma_algo(algo)
+            try:
+                T[algo] = engine.transmission(h, 0, 1, E)
+            finally:
+                engine.set_gamma_algo(0)
+        assert np.max(np.abs(T[0] - T[1])) < 1e-12 * max(1.0, np.max(np.abs(T[1])))
+        for k in (0, 11, 23):
+            sg = [np.asarray(gr.sigma(E[k], i)) for i in (0, 1)]
+            gam = [1j * (x - x.conj().T) for x in sg]
+            tref = oracle.transmission_restricted(E[k], f, s, sg[0] + sg[1], gam[0], gam[1])
+            assert abs(T[0][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
+
+
 @pytest.mark.parametrize("nc", [4, 10, 20])
 def test_chain1d_fixed_trip_count(engine, nc):
     """Same number of sweeps on both sides -> the iterate itself must agree."""
