@@ -48,30 +48,31 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
 #pragma unroll
         for (int c = 0; c < 2; ++c) { accr[a][c] = (d4){0, 0, 0, 0}; acci[a][c] = (d4){0, 0, 0, 0}; }
 
+    // edge blocks: sub-tiles that start beyond M or N do no work (n = 200 pads to 208, not 256)
+    bool va[2], vc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { va[a] = row0 + wr + a * 16 < M; vc[a] = col0 + wc + a * 16 < N; }
+
     // staging assignment: 64 rows x 16 cols, 4 consecutive elements per thread
     const int lr = tid >> 2, lc = (tid & 3) * 4;         // A tile (and B^H tile): row lr, cols lc..lc+3
     const int br = tid >> 4, bc = (tid & 15) * 4;        // B tile (opB=0): row br, cols bc..bc+3
 
-    for (int k0 = 0; k0 < K; k0 += ZG_BK) {
-        // ---- global -> LDS (zero fill outside the matrix)
-        {
-            const int gi = row0 + lr;
+    // global -> registers for the k-tile starting at k0 (zero fill outside the matrix); the tile
+    // after the current one is fetched while the current one runs its MFMAs
+    cplx ra[4], rb[4];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const int gi = row0 + lr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gk = k0 + lc + e;
-                cplx v = cmake(0.0, 0.0);
-                if (gi < M && gk < K) v = A[(size_t)gi * lda + gk];
-                As[lr * ZG_APITCH + lc + e] = v;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int gk = k0 + lc + e;
+            ra[e] = (gi < M && gk < K) ? A[(size_t)gi * lda + gk] : cmake(0.0, 0.0);
         }
         if (opB == 0) {
             const int gk = k0 + br;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int gj = col0 + bc + e;
-                cplx v = cmake(0.0, 0.0);
-                if (gk < K && gj < N) v = B[(size_t)gk * ldb + gj];
-                Bs[br * ZG_BPITCH + bc + e] = v;
+                rb[e] = (gk < K && gj < N) ? B[(size_t)gk * ldb + gj] : cmake(0.0, 0.0);
             }
         } else {
             // op(B)[k][j] = conj(B[j][k]); B stored N x K
@@ -79,12 +80,24 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int gk = k0 + lc + e;
-                cplx v = cmake(0.0, 0.0);
-                if (gj < N && gk < K) v = cconj(B[(size_t)gj * ldb + gk]);
-                Bs[(lc + e) * ZG_BPITCH + lr] = v;
+                rb[e] = (gj < N && gk < K) ? cconj(B[(size_t)gj * ldb + gk]) : cmake(0.0, 0.0);
             }
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += ZG_BK) {
+        // ---- registers -> LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[lr * ZG_APITCH + lc + e] = ra[e];
+        if (opB == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[br * ZG_BPITCH + bc + e] = rb[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[(lc + e) * ZG_BPITCH + lr] = rb[e];
+        }
         __syncthreads();
+        if (k0 + ZG_BK < K) fetch(k0 + ZG_BK);
         // ---- 4 k-steps of 4
 #pragma unroll
         for (int ks = 0; ks < ZG_BK; ks += 4) {
@@ -97,6 +110,7 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
+                    if (!(va[a] && vc[c])) continue;       // 16x16 sub-tile entirely outside the matrix (wave-uniform)
                     accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].x, accr[a][c], 0, 0, 0);
                     accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf[c].y, accr[a][c], 0, 0, 0);
                     acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].y, acci[a][c], 0, 0, 0);
