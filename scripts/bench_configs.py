@@ -136,6 +136,33 @@ def c4():
     return out
 
 
+def c4b():
+    """Bethe-lattice surface self-energy (the Sigma of C4): one Au contact atom, 486 contour + 256
+    real-axis energies, free-running fixed points (bulk 12 directions, then surface 6 directions)."""
+    import os
+    from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix, gen_neighbors, surfGBAt
+    here = os.path.join(ROOT, "tests", "golden", "Au")
+    ne, Ed, Vd, Sd, H0 = read_bethe_params(here)
+    dirs = gen_neighbors(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.2, 0.0]))
+    Sl = [construct_sk_matrix(Sd, d) for d in dirs]; Vl = [construct_sk_matrix(Vd, d) for d in dirs]
+    at = surfGBAt(H0, Sl, Vl, 1e-6)
+    Ec, _ = oracle.contour_grid(-30.0, 0.0, 486, 0.0)
+    Er = np.linspace(-1.0, 1.0, 256)
+    out = {"config": "C4 Sigma: Bethe lattice, Au parameters, eta=1e-6, 486 complex-contour + 256 real-axis energies"}
+    for name, E in (("contour_486", np.asarray(Ec)), ("real_axis_256", Er)):
+        at.sigma(E[:4])
+        t0 = time.perf_counter(); sig = at.sigma(E); t = time.perf_counter() - t0
+        its = np.asarray(at.last_iters)
+        bulk, surf = its & 0xFFFF, its >> 16           # sweeps of the bulk and of the surface fixed point
+        out[name] = {"gpu_s": t, "pts_per_s": len(E) / t, "bulk_sweeps_mean": float(np.mean(bulk)),
+                     "surface_sweeps_mean": float(np.mean(surf)), "sweeps_max": int(max(np.max(bulk), np.max(surf)))}
+    e = complex(Er[100])
+    t0 = time.perf_counter(); ref = oracle.bethe_sigma_surface(e, H0, Sl, Vl, 1e-6); tc = time.perf_counter() - t0
+    out["real_axis_256"]["cpu_pts_per_s"] = 1.0 / tc
+    out["real_axis_256"]["rel_fro_vs_oracle_sample"] = rel(at.sigma(np.array([e]))[0], ref[0])
+    return out
+
+
 def c5():
     N = 1000
     Fa, Sa = random_system(N, 5); Fb, _ = random_system(N, 6)
@@ -171,7 +198,7 @@ def c5():
 
 
 if __name__ == "__main__":
-    want = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
+    want = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c4b", "c5"]
     res = {}
     for name in want:
         t0 = time.perf_counter()
