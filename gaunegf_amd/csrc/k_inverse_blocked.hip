@@ -778,9 +778,14 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
 }
 
 // W[i][J] = (row i pivot of the window ? 0 : W[i][J]) + P'[i][0:cw) * Q[0:cw)[J]  for the column
-// blocks outside the window.  Workgroup = 256 threads = 4 waves, 64 x 64 output block, wave tile
-// 32 x 32 (2 x 2 MFMA tiles), K tile 16 through LDS (same tiling as zgemm_mfma_kernel).
-__global__ __launch_bounds__(256) void gj_bigupdate_kernel(
+// blocks outside the window.  Workgroup = 512 threads = 8 waves, 64 x 64 output block, wave tile
+// 32 x 16 (2 x 1 MFMA tiles, 32 accumulator VGPRs), K tile 16 through LDS.  The product is
+// accumulated from ZERO and the old block is added at the end: its HBM loads are issued before the
+// last k-tile and never sit in front of the matrix pipe; the operand tile after the current one is
+// fetched into registers while the current one runs its MFMAs.
+constexpr int BU_THREADS = 512;
+
+__global__ __launch_bounds__(BU_THREADS, 4) void gj_bigupdate_kernel(
     int n, cplx* __restrict__ bufA, const cplx* __restrict__ bufB, size_t mat_stride,
     const int* __restrict__ piv_all, int c0, int cw)
 {
@@ -793,69 +798,72 @@ __global__ __launch_bounds__(256) void gj_bigupdate_kernel(
     const cplx* Q = bufB + (size_t)blockIdx.z * mat_stride;
     const int* colof = piv_all + (size_t)blockIdx.z * 2 * n + n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int wr = (wave >> 2) * 32, wc = (wave & 3) * 16;
     const int fi = lane & 15, fk = lane >> 4;
-    d4 accr[2][2], acci[2][2];
+    d4 accr[2], acci[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) { accr[a] = (d4){0, 0, 0, 0}; acci[a] = (d4){0, 0, 0, 0}; }
+
+    // staging: A tile 64 x 16 and B tile 16 x 64, two consecutive elements per thread each
+    const int lr = tid >> 3, lc = (tid & 7) * 2;                 // A: row lr, k lc..lc+1
+    const int br = tid >> 5, bc = (tid & 31) * 2;                // B: k br, cols bc..bc+1
+    cplx ra[2], rb[2];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        const int gi = row0 + lr, gk = k0 + br;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int e = 0; e < 2; ++e) {
+            const int ak = k0 + lc + e, gj = col0 + bc + e;
+            ra[e] = (gi < n && ak < cw) ? W[(size_t)gi * n + c0 + ak] : cmake(0.0, 0.0);
+            rb[e] = (gk < cw && gj < n) ? Q[(size_t)gk * n + gj] : cmake(0.0, 0.0);
+        }
+    };
+    // the old block (zero for the pivot rows of this window), requested before the last k-tile
+    cplx cv[2][4];
+    auto fetch_c = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + c * 16 + fi;
-                double vx = 0.0, vy = 0.0;
-                if (gi < n && gj < n) {
-                    const int cf = colof[gi];
-                    if (!(cf >= c0 && cf < c0 + cw)) { const cplx v = W[(size_t)gi * n + gj]; vx = v.x; vy = v.y; }
-                }
-                accr[a][c][r] = vx; acci[a][c][r] = vy;
+                const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + fi;
+                const int gic = min(gi, n - 1), gjc = min(gj, n - 1);
+                const int cf = colof[gic];
+                const cplx v = W[(size_t)gic * n + gjc];
+                const bool z = cf >= c0 && cf < c0 + cw;
+                cv[a][r] = cmake(z ? 0.0 : v.x, z ? 0.0 : v.y);
             }
-    const int lr = tid >> 2, lc = (tid & 3) * 4;                 // A tile staging: row lr, k lc..lc+3
-    const int br = tid >> 4, bc = (tid & 15) * 4;                // B tile staging: k br, cols bc..bc+3
+    };
+    fetch(0);
     for (int k0 = 0; k0 < cw; k0 += BK) {
-        {
-            const int gi = row0 + lr;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gk = k0 + lc + e;
-                As[lr * AP + lc + e] = (gi < n && gk < cw) ? W[(size_t)gi * n + c0 + gk] : cmake(0.0, 0.0);
-            }
-            const int gk = k0 + br;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gj = col0 + bc + e;
-                Bs[br * BP + bc + e] = (gk < cw && gj < n) ? Q[(size_t)gk * n + gj] : cmake(0.0, 0.0);
-            }
-        }
+        for (int e = 0; e < 2; ++e) { As[lr * AP + lc + e] = ra[e]; Bs[br * BP + bc + e] = rb[e]; }
         __syncthreads();
+        if (k0 + BK < cw) fetch(k0 + BK);
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 4) {
-            cplx af[2], bf[2];
+            cplx af[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[a] = As[(wr + a * 16 + fi) * AP + ks + fk];
+            const cplx bf = Bs[(ks + fk) * BP + wc + fi];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) bf[c] = Bs[(ks + fk) * BP + wc + c * 16 + fi];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].x, accr[a][c], 0, 0, 0);
-                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf[c].y, accr[a][c], 0, 0, 0);
-                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].y, acci[a][c], 0, 0, 0);
-                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf[c].x, acci[a][c], 0, 0, 0);
-                }
+            for (int a = 0; a < 2; ++a) {
+                accr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf.x, accr[a], 0, 0, 0);
+                accr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf.y, accr[a], 0, 0, 0);
+                acci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf.y, acci[a], 0, 0, 0);
+                acci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf.x, acci[a], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
+    // (requested after the loop: with the prefetch registers dead the kernel fits 128 VGPRs, two
+    //  workgroups per CU -- the other workgroup covers this latency)
+    fetch_c();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + c * 16 + fi;
-                if (gi < n && gj < n) W[(size_t)gi * n + gj] = cmake(accr[a][c][r], acci[a][c][r]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + fi;
+            if (gi < n && gj < n) W[(size_t)gi * n + gj] = cmake(cv[a][r].x + accr[a][r], cv[a][r].y + acci[a][r]);
+        }
 }
 
 __global__ __launch_bounds__(256) void gj_gather_kernel(int n, const cplx* __restrict__ bufA,
@@ -901,7 +909,7 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     for (int c0 = 0; c0 < n; c0 += WIN) {
         const int cw = min(WIN, n - c0);
         hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, B, stride, piv, info, c0, cw);
-        hipLaunchKernelGGL(gj_bigupdate_kernel, dim3(nblk, nblk, nb), dim3(256), 0, st, n, A, B, stride,
+        hipLaunchKernelGGL(gj_bigupdate_kernel, dim3(nblk, nblk, nb), dim3(BU_THREADS), 0, st, n, A, B, stride,
                            (const int*)piv, c0, cw);
     }
     hipLaunchKernelGGL(gj_gather_kernel, dim3(n, nb), dim3(256), 0, st, n, (const cplx*)A, B, stride,
