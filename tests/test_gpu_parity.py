@@ -121,6 +121,20 @@ def test_api_assertions_and_edges(engine):
         GrLessInt(F, S, g_dev, E, w, 5)
 
 
+def test_largest_window_configuration(engine):
+    """n > 2048 runs the windowed path with 8 rows per lane and sub-panels of 4 columns; one energy,
+    checked through the residual G A = I (an oracle inverse of this size costs seconds of CPU)."""
+    from gaunegf_amd.integrate import GrBatch
+    N = 2100
+    F, S, g_dev, g_ref = _const_provider(N, 77, nc=30)
+    E = np.array([0.4 + 0.05j])
+    G = GrBatch(F, S, g_dev, E)[0]
+    A = E[0] * S - F - np.asarray(g_ref.sigmaTot(E[0]))
+    R = G @ A - np.eye(N)
+    assert np.linalg.norm(R) / np.sqrt(N) < 1e-9
+    assert engine.last_info[0] == 0
+
+
 def test_singular_matrix_is_reported(engine):
     from gaunegf_amd.integrate import GrInt
     from gaunegf_amd.surfGTester import surfGTest
