@@ -35,39 +35,86 @@ struct ChainArgs {
     double eta, conv, relFactor;
     int max_iter, force_iters;
     int b_in_lds;
+    unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), sweep 10
 };
 
-// C tile loop of a small complex GEMM shared by the four waves.  Tiles (ti, tj) of the
-// T16 x T16 grid are dealt to the waves; fa(i,k) / fb(k,j) fetch the operands (zero outside
-// the matrix), c0(i,j) the initial value, out(i,j,v) consumes the result.
-template <class FA, class FB, class FC, class FO>
-__device__ __forceinline__ void small_gemm(int n, int T16, int wave, int lane, FA fa, FB fb, FC c0, FO out)
+// Small complex GEMM shared by the four waves (T16 <= 4 tiles per dimension): wave w owns column
+// tile w and accumulates ALL its row tiles at once -- one B-operand read serves up to four MFMA
+// groups and the four independent accumulator sets keep the matrix pipe busy across the LDS
+// latency.  fa(i,k) / fb(k,j) fetch the operands (zero outside the matrix), c0(i,j) the initial
+// value; the result stays in registers (accr/acci[ti]) for the caller to consume with gemm_store.
+template <int T16, class FA, class FB, class FC>
+__device__ __forceinline__ void small_gemm(int n, int wave, int lane, FA fa, FB fb, FC c0,
+                                           d4 (&accr)[T16], d4 (&acci)[T16])
 {
     const int fi = lane & 15, fk = lane >> 4;
     const int ksteps = (n + 3) >> 2;
-    for (int t = wave; t < T16 * T16; t += CL_WAVES) {
-        const int ti = t / T16, tj = t - ti * T16;
-        d4 accr, acci;
+    const int tj = wave;
+    if (tj >= T16) return;
+#pragma unroll
+    for (int ti = 0; ti < T16; ++ti)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const cplx v = c0(ti * 16 + fk + 4 * r, tj * 16 + fi);
-            accr[r] = v.x; acci[r] = v.y;
+            accr[ti][r] = v.x; acci[ti][r] = v.y;
         }
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const cplx pa = fa(ti * 16 + fi, ks * 4 + fk);
-            const cplx qb = fb(ks * 4 + fk, tj * 16 + fi);
-            zmfma(accr, acci, pa, qb);
-        }
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const cplx qb = fb(ks * 4 + fk, tj * 16 + fi);
+        cplx pa[T16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out(ti * 16 + fk + 4 * r, tj * 16 + fi, cmake(accr[r], acci[r]));
+        for (int ti = 0; ti < T16; ++ti) pa[ti] = fa(ti * 16 + fi, ks * 4 + fk);
+#pragma unroll
+        for (int ti = 0; ti < T16; ++ti) zmfma(accr[ti], acci[ti], pa[ti], qb);
     }
+}
+
+template <int T16, class FO>
+__device__ __forceinline__ void gemm_store(int wave, int lane, const d4 (&accr)[T16], const d4 (&acci)[T16], FO out)
+{
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tj = wave;
+    if (tj >= T16) return;
+#pragma unroll
+    for (int ti = 0; ti < T16; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out(ti * 16 + fk + 4 * r, tj * 16 + fi, cmake(accr[ti][r], acci[ti][r]));
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_key(unsigned long long k)
+{
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > k ? o : k;
+}
+
+// maximum of a 64-bit key over the wave (all lanes active), wave-uniform result
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
+{
+    k = dpp_max_key<0xB1>(k);      // quad_perm [1,0,3,2]
+    k = dpp_max_key<0x4E>(k);      // quad_perm [2,3,0,1]
+    k = dpp_max_key<0x141>(k);     // row_half_mirror
+    k = dpp_max_key<0x140>(k);     // row_mirror
+    unsigned long long best = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, r * 16);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), r * 16);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    return best;
 }
 
 // In-place blocked Gauss-Jordan reduction of the n x n matrix W (LDS, pitch LP) with implicit
 // pivoting.  On return  inv[i][j] = W[pivrow[i]][colof[j]].  All 256 threads call it.
-__device__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][LP]*/, cplx* rowbuf /*[16]*/,
-                              int* pivrow, int* colof, int tid)
+__device__ __forceinline__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][LP]*/, cplx* rowbuf /*[16]*/,
+                              int* pivrow, int* colof, int tid, unsigned long long* st = nullptr)
 {
+    int sti = 0;
+    auto stamp = [&]() __attribute__((always_inline)) { if (st && tid == 0) st[sti] = __builtin_amdgcn_s_memrealtime(); ++sti; };
     const int lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fk = lane >> 4;
     for (int t = tid; t < 64; t += CL_THREADS) { colof[t] = -1; pivrow[t] = 0; }
@@ -75,7 +122,9 @@ __device__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][L
     for (int p0 = 0; p0 < n; p0 += CL_NB) {
         const int pw = min(CL_NB, n - p0);
         if (wave == 0) {
-            // ---- panel: lane = row, 16 complex per lane, no workgroup barrier inside
+            // ---- panel: lane = row, 16 complex per lane; no barrier and no LDS traffic inside:
+            // the pivot search is a DPP max of a packed 64-bit key, the pivot row is spread to all
+            // lanes through v_readlane (the row index is wave-uniform)
             const int r = lane;
             cplx a[CL_NB];
             bool avail = r < n && colof[r] < 0;
@@ -84,38 +133,43 @@ __device__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][L
 #pragma unroll
             for (int j = 0; j < CL_NB; ++j) {
                 if (j < pw) {
-                    double bv = avail ? cabs1(a[j]) : -1.0;
-                    int bkey = avail ? r : 0x7fffffff;
-                    wave_argmax(bv, bkey);
-                    int pphys = bkey;
-                    if (pphys == 0x7fffffff) {                  // NaN column: lowest available row
+                    // key: upper 48 bits of |a|_1 over (63 - row): larger value, then lower row; 0 = none
+                    const double v = cabs1(a[j]);
+                    unsigned long long key = 0;
+                    if (avail && v == v)
+                        key = ((unsigned long long)__double_as_longlong(v) & ~0xFFFFull) | (unsigned long long)(0xFFFF - r);
+                    key = wave_max_key(key);
+                    int pphys;
+                    if (key != 0) {
+                        pphys = 0xFFFF - (int)(key & 0xFFFFull);
+                    } else {                                    // NaN column: lowest available row
                         int cand = avail ? r : 0x7fffffff;
 #pragma unroll
                         for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
                         pphys = cand;
                     }
-                    if (r == pphys) {
-#pragma unroll
-                        for (int s = 0; s < CL_NB; ++s) rowbuf[s] = a[s];
-                        pivrow[p0 + j] = pphys; colof[pphys] = p0 + j;
-                    }
-                    __builtin_amdgcn_wave_barrier();
+                    pphys = __builtin_amdgcn_readfirstlane(pphys);
+                    if (r == pphys) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
                     cplx rb[CL_NB];
 #pragma unroll
-                    for (int s = 0; s < CL_NB; ++s) rb[s] = rowbuf[s];
+                    for (int s = 0; s < CL_NB; ++s) {
+                        rb[s].x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[s].x), pphys),
+                                                   __builtin_amdgcn_readlane(__double2loint(a[s].x), pphys));
+                        rb[s].y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[s].y), pphys),
+                                                   __builtin_amdgcn_readlane(__double2loint(a[s].y), pphys));
+                    }
                     const cplx pv = rb[j];
                     const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
                     const cplx ip = cmake(pv.x * sc, -pv.y * sc);
                     const bool is_piv = r == pphys;
                     const cplx coef = is_piv ? ip : cneg(cmul(a[j], ip));
+                    // pivot row: 0 + (1/pivot) * row ; others: row - (f/pivot) * pivot row.  The
+                    // "0 +" is a multiplication by m = 0 (two v_mul_f64 instead of four selects)
+                    const double m = is_piv ? 0.0 : 1.0;
 #pragma unroll
-                    for (int s = 0; s < CL_NB; ++s) {
-                        const cplx base = is_piv ? cmake(0.0, 0.0) : a[s];
-                        a[s] = cfma(base, coef, rb[s]);
-                    }
+                    for (int s = 0; s < CL_NB; ++s) a[s] = cfma(cmake(a[s].x * m, a[s].y * m), coef, rb[s]);
                     a[j] = coef;
                     avail = avail && !is_piv;
-                    __builtin_amdgcn_wave_barrier();
                 }
             }
             if (r < n) {
@@ -124,13 +178,16 @@ __device__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][L
                     if (s < pw) W[r * LP + p0 + s] = a[s];
             }
         }
+        stamp();
         __syncthreads();                 // P (panel columns of W), pivrow/colof visible
+        stamp();
         // ---- pivot rows -> Q snapshot
         for (int t = tid; t < pw * n; t += CL_THREADS) {
             const int k = t / n, j = t - k * n;
             Qs[k * LP + j] = W[pivrow[p0 + k] * LP + j];
         }
         __syncthreads();
+        stamp();
         // ---- trailing update of the other columns, in place
         const int pt = p0 >> 4;                                   // the panel's column tile
         for (int t = wave; t < T16 * T16; t += CL_WAVES) {
@@ -138,21 +195,25 @@ __device__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][L
             if (tj == pt) continue;
             const int col = tj * 16 + fi;
             d4 accr, acci;
+            const int colc = min(col, n - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                cplx v = cmake(0.0, 0.0);
-                if (i < n && col < n) {
-                    const int cf = colof[i];
-                    if (!(cf >= p0 && cf < p0 + pw)) v = W[i * LP + col];
-                }
-                accr[r] = v.x; acci[r] = v.y;
+                // unconditional loads at clamped indices + selects: no branches in front of the MFMAs
+                const int i = ti * 16 + fk + 4 * r, ic = min(i, n - 1);
+                const int cf = colof[ic];
+                const cplx v = W[ic * LP + colc];
+                const bool keep = (i < n) & (col < n) & !(cf >= p0 && cf < p0 + pw);
+                accr[r] = keep ? v.x : 0.0; acci[r] = keep ? v.y : 0.0;
             }
 #pragma unroll
             for (int ks = 0; ks < CL_NB / 4; ++ks) {
                 const int k = ks * 4 + fk, pr = ti * 16 + fi;
-                const cplx pa = (pr < n && k < pw) ? W[pr * LP + p0 + k] : cmake(0.0, 0.0);
-                const cplx qb = (k < pw && col < n) ? Qs[k * LP + col] : cmake(0.0, 0.0);
+                const int kc = min(k, pw - 1);
+                const cplx pav = W[min(pr, n - 1) * LP + p0 + kc];
+                const cplx qbv = Qs[kc * LP + colc];
+                const bool oka = (pr < n) & (k < pw), okb = (k < pw) & (col < n);
+                const cplx pa = cmake(oka ? pav.x : 0.0, oka ? pav.y : 0.0);
+                const cplx qb = cmake(okb ? qbv.x : 0.0, okb ? qbv.y : 0.0);
                 zmfma(accr, acci, pa, qb);
             }
 #pragma unroll
@@ -162,10 +223,12 @@ __device__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][L
             }
         }
         __syncthreads();
+        stamp();
     }
 }
 
-__global__ __launch_bounds__(CL_THREADS) void chain1d_lds_kernel(
+template <bool B_IN_LDS, int T16>
+__global__ __launch_bounds__(CL_THREADS, 2) void chain1d_lds_kernel(
     ChainArgs a, const cplx* __restrict__ E, cplx* __restrict__ blk, int* __restrict__ iters,
     int* __restrict__ converged)
 {
@@ -177,12 +240,11 @@ __global__ __launch_bounds__(CL_THREADS) void chain1d_lds_kernel(
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = a.nc[c];
     const int off = a.blk_off[c];
-    const int T16 = (n + 15) >> 4;
     const int LP = n | 1;                               // odd pitch; no padded rows: tile accesses are guarded
     cplx* Gs = reinterpret_cast<cplx*>(smem_raw);       // [n][LP] current (mixed) g
     cplx* Ws = Gs + n * LP;                             // [n][LP] work matrix
     cplx* Qs = Ws + n * LP;                             // [16][LP] pivot rows of a panel
-    cplx* Bs = a.b_in_lds ? Qs + CL_NB * LP : nullptr;  // [n][LP] B = (E + i eta) Sb - b, when it fits
+    cplx* Bs = Qs + CL_NB * LP;                         // [n][LP] B = (E + i eta) Sb - b, when it fits (B_IN_LDS)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     const cplx* alpha = a.alpha + off; const cplx* Salpha = a.Salpha + off;
@@ -190,21 +252,32 @@ __global__ __launch_bounds__(CL_THREADS) void chain1d_lds_kernel(
     const cplx* tau = a.tau + off;     const cplx* Stau = a.Stau + off;
     const cplx e = E[b];
     const cplx z = cmake(e.x, e.y + a.eta);
-    auto Aat = [&](int i, int j) { return (i < n && j < n) ? csub(cmul(z, Salpha[i * n + j]), alpha[i * n + j]) : cmake(0.0, 0.0); };
+    // operand fetches: unconditional loads at clamped (always valid) indices, zeroed by a select
+    // outside the matrix -- no branches in the MFMA loops
+    auto sel = [](bool ok, cplx v) { return cmake(ok ? v.x : 0.0, ok ? v.y : 0.0); };
+    auto Aat = [&](int i, int j) {
+        const int o = min(i, n - 1) * n + min(j, n - 1);
+        return sel(i < n && j < n, csub(cmul(z, Salpha[o]), alpha[o]));
+    };
     auto Bglob = [&](int i, int j) { return csub(cmul(z, Sbeta[i * n + j]), beta[i * n + j]); };
     auto Bat = [&](int i, int j) {
-        if (!(i < n && j < n)) return cmake(0.0, 0.0);
-        return Bs ? Bs[i * LP + j] : Bglob(i, j);
+        const int ic = min(i, n - 1), jc = min(j, n - 1);
+        cplx v;
+        if constexpr (B_IN_LDS) v = Bs[ic * LP + jc]; else v = Bglob(ic, jc);
+        return sel(i < n && j < n, v);
     };
-    auto tat = [&](int i, int j) { return (i < n && j < n) ? csub(cmul(e, Stau[i * n + j]), tau[i * n + j]) : cmake(0.0, 0.0); };
-    auto Gat = [&](int i, int j) { return (i < n && j < n) ? Gs[i * LP + j] : cmake(0.0, 0.0); };
-    auto Wat = [&](int i, int j) { return (i < n && j < n) ? Ws[i * LP + j] : cmake(0.0, 0.0); };
+    auto tat = [&](int i, int j) {
+        const int o = min(i, n - 1) * n + min(j, n - 1);
+        return sel(i < n && j < n, csub(cmul(e, Stau[o]), tau[o]));
+    };
+    auto Gat = [&](int i, int j) { return sel(i < n && j < n, Gs[min(i, n - 1) * LP + min(j, n - 1)]); };
+    auto Wat = [&](int i, int j) { return sel(i < n && j < n, Ws[min(i, n - 1) * LP + min(j, n - 1)]); };
 
     // ---- g0 = inv(A)
     for (int t = tid; t < n * n; t += CL_THREADS) {
         const int i = t / n, j = t - i * n;
         Ws[i * LP + j] = Aat(i, j);
-        if (Bs) Bs[i * LP + j] = Bglob(i, j);
+        if constexpr (B_IN_LDS) Bs[i * LP + j] = Bglob(i, j);
     }
     __syncthreads();
     small_inverse(n, T16, Ws, LP, Qs, rowbuf, pivrow, colof, tid);
@@ -219,54 +292,29 @@ __global__ __launch_bounds__(CL_THREADS) void chain1d_lds_kernel(
     while (true) {
         if (a.force_iters >= 0) { if (count >= a.force_iters) break; }
         else if (!(diff > a.conv && count < a.max_iter)) break;
+        unsigned long long* st = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && count == 10) ? a.stamps : nullptr;
+        if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
         // T = B g -> Ws
-        small_gemm(n, T16, wave, lane,
+        d4 mr[T16], mi[T16];
+        small_gemm<T16>(n, wave, lane,
                    [&](int i, int k) { return Bat(i, k); },
                    [&](int k, int j) { return Gat(k, j); },
-                   [&](int, int) { return cmake(0.0, 0.0); },
-                   [&](int i, int j, cplx v) { if (i < n && j < n) Ws[i * LP + j] = v; });
+                   [&](int, int) { return cmake(0.0, 0.0); }, mr, mi);
+        gemm_store<T16>(wave, lane, mr, mi, [&](int i, int j, cplx v) { if (i < n && j < n) Ws[i * LP + j] = v; });
         __syncthreads();
-        // M = A - T B^H : accumulate with the negated left operand; results stay in registers
+        if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+        // M = A - T B^H : accumulate with the negated left operand; the results stay in registers
         // until every wave has finished reading T, then overwrite Ws
-        {
-            const int fi = lane & 15, fk = lane >> 4;
-            const int ksteps = (n + 3) >> 2;
-            d4 mr[4], mi[4];                         // up to 4 tiles per wave (T16 <= 4)
-            int nt = 0;
-            for (int t = wave; t < T16 * T16; t += CL_WAVES, ++nt) {
-                const int ti = t / T16, tj = t - ti * T16;
-                d4 accr, acci;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const cplx v = Aat(ti * 16 + fk + 4 * r, tj * 16 + fi);
-                    accr[r] = v.x; acci[r] = v.y;
-                }
-                for (int ks = 0; ks < ksteps; ++ks) {
-                    const int k = ks * 4 + fk;
-                    const cplx pa = cneg(Wat(ti * 16 + fi, k));                     // -T[i][k]
-                    const cplx qb = cconj(Bat(tj * 16 + fi, k));                    // (B^H)[k][j] = conj(B[j][k])
-                    zmfma(accr, acci, pa, qb);
-                }
-                if (nt == 0) { mr[0] = accr; mi[0] = acci; }
-                else if (nt == 1) { mr[1] = accr; mi[1] = acci; }
-                else if (nt == 2) { mr[2] = accr; mi[2] = acci; }
-                else { mr[3] = accr; mi[3] = acci; }
-            }
-            __syncthreads();
-            nt = 0;
-            for (int t = wave; t < T16 * T16; t += CL_WAVES, ++nt) {
-                const int ti = t / T16, tj = t - ti * T16;
-                const d4 accr = nt == 0 ? mr[0] : (nt == 1 ? mr[1] : (nt == 2 ? mr[2] : mr[3]));
-                const d4 acci = nt == 0 ? mi[0] : (nt == 1 ? mi[1] : (nt == 2 ? mi[2] : mi[3]));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = ti * 16 + fk + 4 * r, j = tj * 16 + fi;
-                    if (i < n && j < n) Ws[i * LP + j] = cmake(accr[r], acci[r]);
-                }
-            }
-        }
+        small_gemm<T16>(n, wave, lane,
+                   [&](int i, int k) { return cneg(Wat(i, k)); },                   // -T[i][k]
+                   [&](int k, int j) { return cconj(Bat(j, k)); },                  // (B^H)[k][j] = conj(B[j][k])
+                   [&](int i, int j) { return Aat(i, j); }, mr, mi);
         __syncthreads();
-        small_inverse(n, T16, Ws, LP, Qs, rowbuf, pivrow, colof, tid);
+        gemm_store<T16>(wave, lane, mr, mi, [&](int i, int j, cplx v) { if (i < n && j < n) Ws[i * LP + j] = v; });
+        __syncthreads();
+        if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+        small_inverse(n, T16, Ws, LP, Qs, rowbuf, pivrow, colof, tid, st ? st + 8 : nullptr);
+        if (st && tid == 0) st[3] = __builtin_amdgcn_s_memrealtime();
         // diff and mixing
         double d = 0.0;
         for (int t = tid; t < n * n; t += CL_THREADS) {
@@ -283,21 +331,25 @@ __global__ __launch_bounds__(CL_THREADS) void chain1d_lds_kernel(
         __syncthreads();
         diff = fmax(fmax(red_v[0], red_v[1]), fmax(red_v[2], red_v[3]));
         __syncthreads();
+        if (st && tid == 0) st[4] = __builtin_amdgcn_s_memrealtime();
         ++count;
     }
     // ---- Sigma_c = t g t^H, t = E Stau - tau (no eta):  X = t g -> Ws ; Sigma = X t^H -> global
-    small_gemm(n, T16, wave, lane,
-               [&](int i, int k) { return tat(i, k); },
-               [&](int k, int j) { return Gat(k, j); },
-               [&](int, int) { return cmake(0.0, 0.0); },
-               [&](int i, int j, cplx v) { if (i < n && j < n) Ws[i * LP + j] = v; });
-    __syncthreads();
-    cplx* out = blk + (size_t)b * a.blk_stride + off;
-    small_gemm(n, T16, wave, lane,
-               [&](int i, int k) { return Wat(i, k); },
-               [&](int k, int j) { return cconj(tat(j, k)); },
-               [&](int, int) { return cmake(0.0, 0.0); },
-               [&](int i, int j, cplx v) { if (i < n && j < n) out[i * n + j] = v; });
+    {
+        d4 xr[T16], xi[T16];
+        small_gemm<T16>(n, wave, lane,
+                   [&](int i, int k) { return tat(i, k); },
+                   [&](int k, int j) { return Gat(k, j); },
+                   [&](int, int) { return cmake(0.0, 0.0); }, xr, xi);
+        gemm_store<T16>(wave, lane, xr, xi, [&](int i, int j, cplx v) { if (i < n && j < n) Ws[i * LP + j] = v; });
+        __syncthreads();
+        cplx* out = blk + (size_t)b * a.blk_stride + off;
+        small_gemm<T16>(n, wave, lane,
+                   [&](int i, int k) { return Wat(i, k); },
+                   [&](int k, int j) { return cconj(tat(j, k)); },
+                   [&](int, int) { return cmake(0.0, 0.0); }, xr, xi);
+        gemm_store<T16>(wave, lane, xr, xi, [&](int i, int j, cplx v) { if (i < n && j < n) out[i * n + j] = v; });
+    }
     if (tid == 0) {
         if (iters) iters[(size_t)b * a.n_contacts + c] = count;
         if (converged) converged[(size_t)b * a.n_contacts + c] = (diff <= a.conv) ? 1 : 0;
@@ -323,11 +375,37 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     size_t smem = (size_t)(2 * n + CL_NB) * LP * sizeof(cplx);
     a.b_in_lds = (smem + (size_t)n * LP * sizeof(cplx) <= limit) ? 1 : 0;
     if (a.b_in_lds) smem += (size_t)n * LP * sizeof(cplx);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chain1d_lds_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-        attr_set = true;
+    static unsigned long long* d_stamps = nullptr;
+    static int want_stamps = -1;
+    if (want_stamps < 0) {
+        want_stamps = getenv("NEGF_CHAIN_STAMPS") ? 1 : 0;
+        if (want_stamps) { (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 64 * sizeof(unsigned long long)); }
     }
-    hipLaunchKernelGGL(chain1d_lds_kernel, dim3(p.n_contacts, nb), dim3(CL_THREADS), smem, st, a, E, blk, iters, conv);
+    a.stamps = d_stamps;
+    // one instantiation per (B in LDS, number of 16-row tiles): compile-time tile loops
+    auto launch = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+        hipLaunchKernelGGL(kern, dim3(p.n_contacts, nb), dim3(CL_THREADS), smem, st, a, E, blk, iters, conv);
+    };
+    const int T16 = (n + 15) >> 4;                    // by the largest contact (smaller ones run padded tiles)
+    if (a.b_in_lds) {
+        if (T16 == 1) launch(chain1d_lds_kernel<true, 1>); else if (T16 == 2) launch(chain1d_lds_kernel<true, 2>);
+        else if (T16 == 3) launch(chain1d_lds_kernel<true, 3>); else launch(chain1d_lds_kernel<true, 4>);
+    } else {
+        if (T16 == 1) launch(chain1d_lds_kernel<false, 1>); else if (T16 == 2) launch(chain1d_lds_kernel<false, 2>);
+        else if (T16 == 3) launch(chain1d_lds_kernel<false, 3>); else launch(chain1d_lds_kernel<false, 4>);
+    }
+    if (d_stamps) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[64];
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        if (h[0]) {
+            auto us = [&](int i) { return h[i] ? (double)(h[i] - h[0]) / 100.0 : -1.0; };
+            fprintf(stderr, "[chain stamps] sweep 10 (us): gemm1 %.2f  gemm2 %.2f  inverse %.2f  diff+mix %.2f | inverse panels:", us(1), us(2), us(3), us(4));
+            for (int i = 8; i < 8 + 16 && h[i]; i += 4)
+                fprintf(stderr, " [factor %.2f sync %.2f qsnap %.2f update %.2f]", (double)(h[i] - h[2]) / 100.0, (double)(h[i + 1] - h[2]) / 100.0,
+                        (double)(h[i + 2] - h[2]) / 100.0, (double)(h[i + 3] - h[2]) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
 }
