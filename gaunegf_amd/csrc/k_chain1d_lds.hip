@@ -110,119 +110,146 @@ __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
 
 // In-place blocked Gauss-Jordan reduction of the n x n matrix W (LDS, pitch LP) with implicit
 // pivoting.  On return  inv[i][j] = W[pivrow[i]][colof[j]].  All 256 threads call it.
+// Panels of 16 columns with look-ahead: at stage s all waves first apply panel s to the column
+// tile of panel s+1, then wave 0 factors panel s+1 while waves 1-3 apply panel s to the remaining
+// column tiles.
 __device__ __forceinline__ void small_inverse(int n, int T16, cplx* W, int LP, cplx* Qs /*[16][LP]*/, cplx* rowbuf /*[16]*/,
                               int* pivrow, int* colof, int tid, unsigned long long* st = nullptr)
 {
+    (void)rowbuf;
     int sti = 0;
     auto stamp = [&]() __attribute__((always_inline)) { if (st && tid == 0) st[sti] = __builtin_amdgcn_s_memrealtime(); ++sti; };
     const int lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fk = lane >> 4;
     for (int t = tid; t < 64; t += CL_THREADS) { colof[t] = -1; pivrow[t] = 0; }
     __syncthreads();
-    for (int p0 = 0; p0 < n; p0 += CL_NB) {
-        const int pw = min(CL_NB, n - p0);
-        if (wave == 0) {
-            // ---- panel: lane = row, 16 complex per lane; no barrier and no LDS traffic inside:
-            // the pivot search is a DPP max of a packed 64-bit key, the pivot row is spread to all
-            // lanes through v_readlane (the row index is wave-uniform)
-            const int r = lane;
-            cplx a[CL_NB];
-            bool avail = r < n && colof[r] < 0;
+
+    // ---- panel [p0, p0+pw): lane = row, 16 complex per lane; no barrier and no LDS traffic inside:
+    // the pivot search is a DPP max of a packed 64-bit key, the pivot row is spread to all lanes
+    // through v_readlane (the row index is wave-uniform).  A pivot row is not scaled at its column
+    // step (multiplier 0, a one in the pivot column) but once at the end of the panel: the later
+    // steps act linearly on it, and every lane runs the same select-free update.
+    auto factor = [&](int p0, int pw) __attribute__((always_inline)) {
+        const int r = lane;
+        cplx a[CL_NB];
+        bool avail = r < n && colof[r] < 0;
+        cplx myip = cmake(1.0, 0.0);
 #pragma unroll
-            for (int s = 0; s < CL_NB; ++s) a[s] = (r < n && s < pw) ? W[r * LP + p0 + s] : cmake(0.0, 0.0);
+        for (int s = 0; s < CL_NB; ++s) a[s] = (r < n && s < pw) ? W[r * LP + p0 + s] : cmake(0.0, 0.0);
 #pragma unroll
-            for (int j = 0; j < CL_NB; ++j) {
-                if (j < pw) {
-                    // key: upper 48 bits of |a|_1 over (63 - row): larger value, then lower row; 0 = none
-                    const double v = cabs1(a[j]);
-                    unsigned long long key = 0;
-                    if (avail && v == v)
-                        key = ((unsigned long long)__double_as_longlong(v) & ~0xFFFFull) | (unsigned long long)(0xFFFF - r);
-                    key = wave_max_key(key);
-                    int pphys;
-                    if (key != 0) {
-                        pphys = 0xFFFF - (int)(key & 0xFFFFull);
-                    } else {                                    // NaN column: lowest available row
-                        int cand = avail ? r : 0x7fffffff;
+        for (int j = 0; j < CL_NB; ++j) {
+            if (j < pw) {
+                // key: upper 48 bits of |a|_1 over (0xFFFF - row): larger value, then lower row; 0 = none
+                const double v = cabs1(a[j]);
+                unsigned long long key = 0;
+                if (avail && v == v)
+                    key = ((unsigned long long)__double_as_longlong(v) & ~0xFFFFull) | (unsigned long long)(0xFFFF - r);
+                key = wave_max_key(key);
+                int pphys;
+                if (key != 0) {
+                    pphys = 0xFFFF - (int)(key & 0xFFFFull);
+                } else {                                    // NaN column: lowest available row
+                    int cand = avail ? r : 0x7fffffff;
 #pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
-                        pphys = cand;
-                    }
-                    pphys = __builtin_amdgcn_readfirstlane(pphys);
-                    if (r == pphys) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
-                    cplx rb[CL_NB];
-#pragma unroll
-                    for (int s = 0; s < CL_NB; ++s) {
-                        rb[s].x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[s].x), pphys),
-                                                   __builtin_amdgcn_readlane(__double2loint(a[s].x), pphys));
-                        rb[s].y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[s].y), pphys),
-                                                   __builtin_amdgcn_readlane(__double2loint(a[s].y), pphys));
-                    }
-                    const cplx pv = rb[j];
-                    const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
-                    const cplx ip = cmake(pv.x * sc, -pv.y * sc);
-                    const bool is_piv = r == pphys;
-                    const cplx coef = is_piv ? ip : cneg(cmul(a[j], ip));
-                    // pivot row: 0 + (1/pivot) * row ; others: row - (f/pivot) * pivot row.  The
-                    // "0 +" is a multiplication by m = 0 (two v_mul_f64 instead of four selects)
-                    const double m = is_piv ? 0.0 : 1.0;
-#pragma unroll
-                    for (int s = 0; s < CL_NB; ++s) a[s] = cfma(cmake(a[s].x * m, a[s].y * m), coef, rb[s]);
-                    a[j] = coef;
-                    avail = avail && !is_piv;
+                    for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
+                    pphys = cand;
                 }
-            }
-            if (r < n) {
+                pphys = __builtin_amdgcn_readfirstlane(pphys);
+                if (r == pphys) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
+                cplx rb[CL_NB];
 #pragma unroll
-                for (int s = 0; s < CL_NB; ++s)
-                    if (s < pw) W[r * LP + p0 + s] = a[s];
+                for (int s = 0; s < CL_NB; ++s) {
+                    rb[s].x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[s].x), pphys),
+                                               __builtin_amdgcn_readlane(__double2loint(a[s].x), pphys));
+                    rb[s].y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[s].y), pphys),
+                                               __builtin_amdgcn_readlane(__double2loint(a[s].y), pphys));
+                }
+                const cplx pv = rb[j];
+                const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+                const cplx ip = cmake(pv.x * sc, -pv.y * sc);
+                const bool is_piv = r == pphys;
+                const cplx mf = cneg(cmul(a[j], ip));
+                const cplx coef = cmake(is_piv ? 0.0 : mf.x, is_piv ? 0.0 : mf.y);
+#pragma unroll
+                for (int s = 0; s < CL_NB; ++s) a[s] = cfma(a[s], coef, rb[s]);
+                a[j] = is_piv ? cmake(1.0, 0.0) : coef;
+                myip = cmake(is_piv ? ip.x : myip.x, is_piv ? ip.y : myip.y);
+                avail = avail && !is_piv;
+            }
+        }
+        if (r < n) {
+#pragma unroll
+            for (int s = 0; s < CL_NB; ++s)
+                if (s < pw) W[r * LP + p0 + s] = cmul(a[s], myip);       // the deferred pivot-row scaling
+        }
+    };
+
+    // ---- trailing update of tile (ti, tj) with panel [p0, p0+pw), in place:
+    //      W[i][col] = (i pivot row of the panel ? 0 : W[i][col]) + P[i][:] Q[:][col]
+    auto update_tile = [&](int ti, int tj, int p0, int pw) __attribute__((always_inline)) {
+        const int col = tj * 16 + fi;
+        d4 accr, acci;
+        const int colc = min(col, n - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // unconditional loads at clamped indices + selects: no branches in front of the MFMAs
+            const int i = ti * 16 + fk + 4 * r, ic = min(i, n - 1);
+            const int cf = colof[ic];
+            const cplx v = W[ic * LP + colc];
+            const bool keep = (i < n) & (col < n) & !(cf >= p0 && cf < p0 + pw);
+            accr[r] = keep ? v.x : 0.0; acci[r] = keep ? v.y : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < CL_NB / 4; ++ks) {
+            const int k = ks * 4 + fk, pr = ti * 16 + fi;
+            const int kc = min(k, pw - 1);
+            const cplx pav = W[min(pr, n - 1) * LP + p0 + kc];
+            const cplx qbv = Qs[kc * LP + colc];
+            const bool oka = (pr < n) & (k < pw), okb = (k < pw) & (col < n);
+            const cplx pa = cmake(oka ? pav.x : 0.0, oka ? pav.y : 0.0);
+            const cplx qb = cmake(okb ? qbv.x : 0.0, okb ? qbv.y : 0.0);
+            zmfma(accr, acci, pa, qb);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + fk + 4 * r;
+            if (i < n && col < n) W[i * LP + col] = cmake(accr[r], acci[r]);
+        }
+    };
+
+    const int npanels = (n + CL_NB - 1) / CL_NB;
+    for (int sgi = -1; sgi < npanels; ++sgi) {
+        const bool has_cur = sgi >= 0, has_next = sgi + 1 < npanels;
+        const int p0 = has_cur ? sgi * CL_NB : 0, pw = has_cur ? min(CL_NB, n - p0) : 0;
+        const int n0 = (sgi + 1) * CL_NB, nw = has_next ? min(CL_NB, n - n0) : 0;
+        if (has_cur) {
+            // pivot rows of panel sgi -> Q snapshot
+            for (int t = tid; t < pw * n; t += CL_THREADS) {
+                const int k = t / n, j = t - k * n;
+                Qs[k * LP + j] = W[pivrow[p0 + k] * LP + j];
+            }
+            __syncthreads();
+            stamp();
+            if (has_next) {
+                // look-ahead: the column tile of panel sgi+1, one row tile per wave
+                for (int ti = wave; ti < T16; ti += CL_WAVES) update_tile(ti, sgi + 1, p0, pw);
+                __syncthreads();
+            }
+        }
+        if (wave == 0 && has_next) {
+            factor(n0, nw);
+        } else if (has_cur) {
+            // the other column tiles: waves 1-3 while wave 0 factors, all four after the last panel
+            const int team = has_next ? CL_WAVES - 1 : CL_WAVES, me = has_next ? wave - 1 : wave;
+            int cnt = 0;
+            for (int t = 0; t < T16 * T16; ++t) {
+                const int ti = t / T16, tj = t - ti * T16;
+                if (tj == sgi || (has_next && tj == sgi + 1)) continue;
+                if (cnt++ % team == me) update_tile(ti, tj, p0, pw);
             }
         }
         stamp();
-        __syncthreads();                 // P (panel columns of W), pivrow/colof visible
-        stamp();
-        // ---- pivot rows -> Q snapshot
-        for (int t = tid; t < pw * n; t += CL_THREADS) {
-            const int k = t / n, j = t - k * n;
-            Qs[k * LP + j] = W[pivrow[p0 + k] * LP + j];
-        }
-        __syncthreads();
-        stamp();
-        // ---- trailing update of the other columns, in place
-        const int pt = p0 >> 4;                                   // the panel's column tile
-        for (int t = wave; t < T16 * T16; t += CL_WAVES) {
-            const int ti = t / T16, tj = t - ti * T16;
-            if (tj == pt) continue;
-            const int col = tj * 16 + fi;
-            d4 accr, acci;
-            const int colc = min(col, n - 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // unconditional loads at clamped indices + selects: no branches in front of the MFMAs
-                const int i = ti * 16 + fk + 4 * r, ic = min(i, n - 1);
-                const int cf = colof[ic];
-                const cplx v = W[ic * LP + colc];
-                const bool keep = (i < n) & (col < n) & !(cf >= p0 && cf < p0 + pw);
-                accr[r] = keep ? v.x : 0.0; acci[r] = keep ? v.y : 0.0;
-            }
-#pragma unroll
-            for (int ks = 0; ks < CL_NB / 4; ++ks) {
-                const int k = ks * 4 + fk, pr = ti * 16 + fi;
-                const int kc = min(k, pw - 1);
-                const cplx pav = W[min(pr, n - 1) * LP + p0 + kc];
-                const cplx qbv = Qs[kc * LP + colc];
-                const bool oka = (pr < n) & (k < pw), okb = (k < pw) & (col < n);
-                const cplx pa = cmake(oka ? pav.x : 0.0, oka ? pav.y : 0.0);
-                const cplx qb = cmake(okb ? qbv.x : 0.0, okb ? qbv.y : 0.0);
-                zmfma(accr, acci, pa, qb);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                if (i < n && col < n) W[i * LP + col] = cmake(accr[r], acci[r]);
-            }
-        }
-        __syncthreads();
+        __syncthreads();                 // panel sgi+1 (columns of W, pivrow/colof) and the update complete
         stamp();
     }
 }
@@ -402,9 +429,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
         if (h[0]) {
             auto us = [&](int i) { return h[i] ? (double)(h[i] - h[0]) / 100.0 : -1.0; };
             fprintf(stderr, "[chain stamps] sweep 10 (us): gemm1 %.2f  gemm2 %.2f  inverse %.2f  diff+mix %.2f | inverse panels:", us(1), us(2), us(3), us(4));
-            for (int i = 8; i < 8 + 16 && h[i]; i += 4)
-                fprintf(stderr, " [factor %.2f sync %.2f qsnap %.2f update %.2f]", (double)(h[i] - h[2]) / 100.0, (double)(h[i + 1] - h[2]) / 100.0,
-                        (double)(h[i + 2] - h[2]) / 100.0, (double)(h[i + 3] - h[2]) / 100.0);
+            for (int i = 8; i < 8 + 24 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[2]) / 100.0);
             fprintf(stderr, "\n");
         }
     }
