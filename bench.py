@@ -73,6 +73,7 @@ def cpu_baseline(F, S, inds, E, w, budget_s=12.0):
     except Exception:
         threadpool_limits = None
     best_t, best_per = ncpu, None
+    by_threads = {}
     cands = sorted({t for t in (1, 4, 8, 16, 32, 64, ncpu) if t <= ncpu}) if threadpool_limits else [ncpu]
     for t in cands:
         ctx = threadpool_limits(limits=t) if threadpool_limits else None
@@ -84,6 +85,7 @@ def cpu_baseline(F, S, inds, E, w, budget_s=12.0):
         finally:
             if ctx is not None:
                 ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
+        by_threads[str(t)] = round(1.0 / per, 2)
         if best_per is None or per < best_per:
             best_t, best_per = t, per
     n = int(max(16, min(len(E), budget_s / max(best_per, 1e-6))))
@@ -100,6 +102,7 @@ def cpu_baseline(F, S, inds, E, w, budget_s=12.0):
         if ctx is not None:
             ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
     return {"value": n * passes / dt, "unit": "energy-points/s", "cores": int(best_t), "kind": "port",
+            "points_per_s_by_blas_threads": by_threads,      # 6-point probes; "1" is the scalar figure
             "sample": f"{passes} x {n} of {len(E)} energies of the same N_orb={F.shape[0]} workload, numpy {np.__version__} "
                       f"solve(A,I) loop (oracle.GrInt), best of BLAS threads {cands} = {best_t} "
                       f"(host has {ncpu} logical CPUs), {dt:.2f} s"}

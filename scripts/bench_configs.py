@@ -116,23 +116,50 @@ def c3():
     return out
 
 
+def _bethe_contacts(N):
+    """Geometry of C4's contacts: 2 contacts x 3 Au atoms x 9 orbitals at the two ends of
+    an N-orbital device; the remaining orbitals belong to one device 'atom'."""
+    coords = np.array([[0, 0, 0.0], [2.88, 0, 0], [1.44, 2.494, 0],
+                       [0, 0, 20.0], [2.88, 0, 20.0], [1.44, 2.494, 20.0],
+                       [1.44, 0.8, 10.0]])
+    orbMap = np.concatenate([np.full(9, a + 1) for a in range(6)] + [np.full(N - 54, 7)])
+    typ_one = np.array([0, 1001, 1002, 1003, 2001, 2002, 2003, 2004, 2005])
+    orbTyp = np.concatenate([typ_one] * 6 + [np.zeros(N - 54, dtype=int)])
+    return coords, orbMap, orbTyp
+
+
 def c4():
+    from gaunegf_amd.surfGBethe import surfGB
     N = 800
     F, S = random_system(N, 4)
-    nc = 27
-    inds = [list(range(nc)), list(range(N - nc, N))]
-    g = surfGTest(F, S, inds, -0.1j); ref = oracle.ConstSigma(F, S, inds, -0.1j)
-    out = {"config": "C4 (inverse part): N=800, contour ANT N=486 (T=0) + real axis N2=256; Bethe Sigma replaced "
-                     "by constant contacts here (the Bethe kernel is timed separately)"}
+    coords, orbMap, orbTyp = _bethe_contacts(N)
+    lat = os.path.join(ROOT, "tests", "golden", "Au")
+    t0 = time.perf_counter()
+    g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
+    t_setup = time.perf_counter() - t0
+    out = {"config": "C4: N=800, Bethe-lattice Sigma (Au.bethe, 2 contacts x 3 atoms x 9 orbitals, eta=1e-6), "
+                     "contour ANT N=486 (T=0) + real axis N2=256",
+           "host_setup_s": t_setup, "orthogonalised_Sigma": bool(g.Sdict['sss'] == 0)}
     t, P = timed(lambda: D.densityComplexN(F, S, g, -8.0, 0.0, 486, 0.0, showText=False), reps=1)
-    E, w = oracle.contour_grid(-8.0, 0.0, 486, 0.0)
-    sub = np.arange(0, 486, 60)
-    rate, ro = cpu_rate(lambda: oracle.GrInt(F, S, ref, E[sub], w[sub]), len(sub))
-    out["densityComplexN_486"] = {"gpu_s": t, "gpu_pts_per_s": 486 / t, "cpu_pts_per_s": rate,
-                                  "rel_fro_vs_oracle_sample": rel(GrInt(F, S, g, E[sub], w[sub]), ro),
-                                  "gpu_tflops": 8.0 * N ** 3 * 486 / t / 1e12}
+    out["densityComplexN_486"] = {"gpu_s": t, "gpu_pts_per_s": 486 / t, "gpu_tflops_inverse_only": 8.0 * N ** 3 * 486 / t / 1e12}
     t, P2 = timed(lambda: D.densityRealN(F, S, g, -1e6, -8.0, 256, 0.0, showText=False), reps=1)
     out["densityRealN_256"] = {"gpu_s": t, "gpu_pts_per_s": 256 / t}
+    # oracle sample: 3 contour points with the oracle's own Bethe fixed point at the same trip count
+    E, w = oracle.contour_grid(-8.0, 0.0, 486, 0.0)
+    sub = np.array([0, 243, 485])
+    Xi = g.Xi if g.Sdict['sss'] == 0 else None
+    g.force_iters = 30
+
+    class Ref:
+        def sigma(self, E_, i, conv=None):
+            at = g.gList[i]
+            return oracle.bethe_contact_sigma(E_, N, g.indsLists[i], g.nIndLists[i], at.H, at.Slist, at.Vlist,
+                                              1e-6, Xi=Xi, force_iters=30)
+        def sigmaTot(self, E_, conv=None): return self.sigma(E_, 0) + self.sigma(E_, 1)
+    rate, ro = cpu_rate(lambda: oracle.GrInt(F, S, Ref(), E[sub], w[sub]), len(sub))
+    out["densityComplexN_486"]["cpu_pts_per_s"] = rate
+    out["densityComplexN_486"]["rel_fro_vs_oracle_sample_fixed_trip"] = rel(GrInt(F, S, g, E[sub], w[sub]), ro)
+    g.force_iters = -1
     return out
 
 
@@ -191,6 +218,11 @@ def c5():
     t0 = time.perf_counter(); eng.gless_int(h, -1, E2, w2); t2 = time.perf_counter() - t0
     out["GrLessInt_ind-1_256pts"] = {"gpu_s": t2, "gpu_pts_per_s": M2 / t2, "gpu_tflops": 24.0 * (2 * N) ** 3 * M2 / t2 / 1e12,
                                      "batch_in_flight": eng.get_batch() if hasattr(eng, "get_batch") else None}
+    # transmission, spin 'u' blocks (transport.py:159-181) on the same 2N x 2N system
+    Et = np.linspace(-0.25, 0.25, M)
+    eng.transmission(h, 0, 1, Et, spin_block=True)
+    t0 = time.perf_counter(); Tt, Ts = eng.transmission(h, 0, 1, Et, spin_block=True); t3 = time.perf_counter() - t0
+    out["transmission_spin_u"] = {"gpu_s": t3, "gpu_pts_per_s": M / t3}
     sub = [0, M // 2]
     rate, ro = cpu_rate(lambda: oracle.GrLessInt(F, S, G(), E[sub], w[sub], -1), len(sub))
     out["GrLessInt_ind-1"]["cpu_pts_per_s"] = rate
