@@ -1,0 +1,201 @@
+"""
+Density step of the energy-dependent NEGF-SCF cycle without Gaussian -- the part of
+``gauNEGF/scfE.py`` that drives the energy-grid hot path.
+
+    NEGFE.setVoltage          scf.py:318-370 (chemical potentials; the E-field pushed into the
+                              Gaussian interface is not part of this class) + scfE.py:183-205
+    NEGFE.setIntegralLimits   scfE.py:207-232
+    NEGFE.getHOMOLUMO         scf.py:297-316
+    NEGFE.getSigma            scfE.py:283-298
+    NEGFE.FockToP             scfE.py:301-462   (contour + real-axis + bias-window integrals,
+                                                 Fermi search, level occupations)
+    NEGFE.SCF                 a plain damped loop around FockToP / a caller-supplied Fock builder
+                              (the reference's PToFock calls Gaussian, scf.py:520-595)
+
+The reference keeps F in Hartree and multiplies by ``har_to_eV`` at every use; here the Fock
+matrix is handed over (and stored) in eV.  ``ne`` is the electron count the search aims for
+(``bar.ne``; halved internally for spin 'r' exactly as scfE.py:374-376).  The 'predict' Fermi
+method needs the analytic, grid-free ``density()`` (density.py:276-382, out of scope) and raises.
+Every integral runs on the GPU engine through ``gaunegf_amd.density``.
+"""
+import numpy as np
+from scipy.linalg import fractional_matrix_power
+
+from .config import ADAPTIVE_INTEGRATION_TOL, ENERGY_MIN, FERMI_CALCULATION_TOL, TEMPERATURE
+from .density import (calcEmin, calcFermiBisect, calcFermiMuller, calcFermiPolyFit, calcFermiSecant,
+                      densityComplex, densityComplexN, densityGrid, densityGridN, densityReal,
+                      densityRealN, integralFit, integralFitNEGF)
+
+har_to_eV = 27.211386   # eV/Hartree (scfE.py:44)
+
+
+class NEGFE:
+    def __init__(self, F_eV, S, g, ne, spin='r', T=TEMPERATURE, Eminf=ENERGY_MIN, fock_builder=None):
+        """``g``: contact object with the reference's protocol (sigma, sigmaTot, setF, F, S);
+        ``fock_builder(P) -> F_eV``: optional model replacing Gaussian's PToFock for ``SCF``."""
+        self.F = np.array(F_eV)
+        self.S = np.array(S)
+        self.g = g
+        self.ne = ne
+        self.spin = spin
+        self.T = T
+        self.Eminf = Eminf
+        self.fock_builder = fock_builder
+        self.X = np.array(fractional_matrix_power(self.S, -0.5))            # scf.py:181
+        self.fermi = None
+        self.updFermi = False
+        self.fermiMethod = 'muller'
+        self.qV = 0.0
+        self.mu1 = self.mu2 = None
+        self.convLevel = 9999.0
+        self.P = None
+        self.setIntegralLimits(Emin=0.0, tol=None)                          # placeholders until setVoltage
+        self.tol = ADAPTIVE_INTEGRATION_TOL
+
+    # ------------------------------------------------------------------ set-up
+    def nelec_target(self):
+        return self.ne / 2 if self.spin == 'r' else self.ne                 # scfE.py:374-376
+
+    def getHOMOLUMO(self):
+        orbs = np.sort(np.linalg.eigvals(self.X @ self.F @ self.X))         # scf.py:310-311 (F already in eV)
+        n = int(round(self.nelec_target()))
+        return np.real(orbs[n - 1:n + 1])
+
+    def setVoltage(self, qV, fermi=np.nan, Emin=None, Eminf=None, fermiMethod='muller'):
+        if np.isnan(fermi):                                                 # scf.py:349-357
+            self.updFermi = True
+            fermi = float(np.sum(self.getHOMOLUMO()) / 2) if self.fermi is None else self.fermi
+        else:
+            self.updFermi = False
+        if Emin is not None:
+            self.Emin = Emin
+        if Eminf is not None:
+            self.Eminf = Eminf
+        self.fermi = fermi
+        self.qV = qV
+        self.mu1 = fermi + qV / 2
+        self.mu2 = fermi - qV / 2
+        self.g.setF(self.F, self.mu1, self.mu2)                             # scfE.py:200
+        if self.mu1 != self.mu2 and self.N1 is not None:
+            self.Nnegf = 50                                                 # scfE.py:201-202
+        if self.updFermi:
+            self.fermiMethod = fermiMethod
+
+    def setIntegralLimits(self, N1=None, N2=None, Nnegf=None, tol=ADAPTIVE_INTEGRATION_TOL, Emin=None):
+        if Emin is None and tol is not None:                                # scfE.py:224-227
+            self.Emin = calcEmin(self.F, self.S, self.g)
+        else:
+            self.Emin = Emin
+        self.tol = tol
+        self.N1 = N1
+        self.N2 = N2
+        self.Nnegf = Nnegf
+
+    def fitIntegralLimits(self):
+        """The limit-fitting half of integralCheck (scfE.py:262-270): Emin, N1, N2 (and Nnegf under bias)."""
+        self.Emin, self.N1, self.N2 = integralFit(self.F, self.S, self.g, self.fermi, self.Eminf, self.tol)
+        if self.mu1 != self.mu2:
+            self.Nnegf = integralFitNEGF(self.F, self.S, self.g, self.fermi, self.qV, self.Eminf, self.tol, self.T)
+
+    def getSigma(self, E):
+        return (self.g.sigma(E, 0), self.g.sigma(E, -1))
+
+    # ------------------------------------------------------------------ the density step
+    def FockToP(self):
+        """Density matrix for the current Fock matrix (scfE.py:301-462).  Returns the sorted
+        orbital energies and their occupations; ``self.P`` holds the density matrix."""
+        F, S, g = self.F, self.S, self.g
+        if self.N2 is None:                                                 # scfE.py:316-320
+            self.Emin = calcEmin(F, S, g)
+            P = densityReal(F, S, g, self.Eminf, self.Emin, self.tol, T=0)
+        else:
+            P = densityRealN(F, S, g, self.Eminf, self.Emin, self.N2, T=0, showText=False)
+        nLower = np.trace(S @ P).real
+
+        def compContourP2(mu):                                              # scfE.py:324-328
+            if self.N1 is not None:
+                return densityComplexN(F, S, g, self.Emin, mu, N=self.N1, T=self.T, showText=False)
+            return densityComplex(F, S, g, self.Emin, mu, tol=self.tol, T=self.T)
+
+        if self.updFermi:
+            fermi_old = self.fermi + 0.0
+            conv = min(self.convLevel, FERMI_CALCULATION_TOL)
+            method = self.fermiMethod.lower()
+            if method == 'predict':
+                raise NotImplementedError("fermiMethod 'predict' needs the analytic density() (density.py:276-382), "
+                                          "which is outside the energy-grid path")
+            if method not in ('muller', 'secant', 'bisect', 'poly'):
+                raise Exception("Error: invalid Fermi search method, needs to be 'muller', 'secant', 'bisect' "
+                                "or 'predict' or 'default'")
+            methodFail = False
+            uBound = lBound = None
+            ne = self.nelec_target()
+            same_mu = self.mu1 == self.mu2
+            if method == 'poly':                                            # scfE.py:371-387
+                self.fermi, dE, P2, dN, uBound, lBound = calcFermiPolyFit(g, ne - nLower, self.Emin, fermi_old,
+                                                                         self.N1, tol=self.tol, conv=conv, T=self.T)
+                methodFail = dN > conv
+            elif method == 'muller':                                        # scfE.py:389-405
+                self.fermi, dE, P2, dN, uBound, lBound = calcFermiMuller(g, ne - nLower, self.Emin, fermi_old,
+                                                                        self.N1, tol=self.tol, conv=conv, T=self.T)
+                methodFail = dN > conv
+            elif method == 'secant':                                        # scfE.py:407-423
+                self.fermi, dE, P2, dN = calcFermiSecant(g, ne - nLower, self.Emin, fermi_old, self.N1,
+                                                         tol=self.tol, conv=conv, T=self.T)
+                methodFail = dN > conv
+            if method != 'bisect':
+                if methodFail:
+                    print(f'Switching to BISECT method (Fermi error = {dE:.2E} eV)')
+                    fermi_old = self.fermi + 0.0
+                else:
+                    print(f'Fermi Energy set to {self.fermi:.2f} eV, error = {dE:.2E} eV ')
+                    P = P + P2 if same_mu else P + compContourP2(self.mu1)
+            if method == 'bisect' or methodFail:                            # scfE.py:425-435
+                self.fermi, dE, P2 = calcFermiBisect(g, ne - nLower, self.Emin, fermi_old, self.N1, tol=self.tol,
+                                                     conv=conv, T=self.T, uBound=uBound, lBound=lBound)
+                print(f'Fermi Energy set to {self.fermi:.2f} eV, error = {dE:.2E} eV ')
+                P = P + P2 if same_mu else P + compContourP2(self.mu1)
+            # shift Emin, mu1, mu2 and refresh the contact self-energies (scfE.py:440-443)
+            self.setVoltage(self.qV, fermiMethod=self.fermiMethod)
+            self.Emin += self.fermi - fermi_old
+            self.g.setF(F, self.mu1, self.mu2)
+        else:
+            P = P + compContourP2(self.mu1)                                 # scfE.py:444-446
+
+        if self.mu1 != self.mu2:                                            # scfE.py:449-457
+            if self.Nnegf is not None:
+                P = P + densityGridN(F, S, g, self.mu1, self.mu2, ind=-1, N=self.Nnegf, T=self.T, showText=False)
+            else:
+                P = P + densityGrid(F, S, g, self.mu1, self.mu2, ind=-1, tol=self.tol, T=self.T)
+
+        # level occupations in the Lowdin basis (scfE.py:460-468)
+        D, V = np.linalg.eigh(self.X @ F @ self.X)
+        Xi = np.linalg.inv(self.X)
+        pshift = V.conj().T @ (Xi @ P @ Xi) @ V
+        self.P = np.array(P)
+        occList = np.diag(np.real(pshift))
+        EList = np.array(np.real(D)).flatten()
+        inds = np.argsort(EList)
+        return EList[inds], occList[inds]
+
+    # ------------------------------------------------------------------ a model SCF loop
+    def SCF(self, conv=1e-5, damping=0.02, maxcycles=100):
+        """Damped fixed point F <- fock_builder(P) around FockToP (the loop structure of scf.py:663-760
+        with a caller-supplied Fock model instead of Gaussian).  Returns the list of density changes."""
+        if self.fock_builder is None:
+            raise RuntimeError("SCF needs fock_builder(P) -> F in eV (Gaussian is not available here)")
+        history = []
+        P_old = self.P
+        for _ in range(maxcycles):
+            self.FockToP()
+            if P_old is not None:
+                dP = float(np.max(np.abs(self.P - P_old)))
+                history.append(dP)
+                self.convLevel = dP
+                if dP < conv:
+                    break
+                self.P = P_old + damping * (self.P - P_old)
+            P_old = self.P
+            self.F = np.array(self.fock_builder(self.P))
+            self.g.setF(self.F, self.mu1, self.mu2)
+        return history

@@ -566,6 +566,58 @@ def test_density_front_ends(engine):
     assert 0 < ne < 40
 
 
+def test_fock_to_p_density_step(engine, capsys):
+    """scfE.NEGFE.FockToP (scfE.py:301-462) without Gaussian: with a given Fermi level the density
+    matrix is the sum of the real-axis, contour (+ broadening) and bias-window integrals with the
+    reference's prefactors -- checked against the same sum built from the oracle's grids and
+    integrals; with the Fermi search switched on the electron count lands on the target."""
+    from gaunegf_amd.scfE import NEGFE
+    N = 24
+    F, S, g_dev, g_ref = _const_provider(N, 11, nc=4)
+    T, N1, N2, Nn = 300.0, 30, 12, 10
+    Emin, Eminf, mu = -7.0, -60.0, 0.15
+
+    def ref_P(mu1, mu2):
+        E, w = oracle.real_axis_grid(Eminf, Emin, N2, 0.0)
+        P = -np.imag(oracle.GrInt(F, S, g_ref, E, w)) / np.pi
+        E, w = oracle.contour_grid(Emin, mu1, N1, T); Eb, wb = oracle.broadening_grid(mu1, N1, T)
+        P = P + np.imag(oracle.GrInt(F, S, g_ref, E, w) + oracle.GrInt(F, S, g_ref, Eb, wb)) / np.pi
+        if mu1 != mu2:
+            E, w = oracle.bias_window_grid(mu1, mu2, Nn, T)
+            P = P + oracle.GrLessInt(F, S, g_ref, E, w, -1) / (2 * np.pi)
+        return P
+
+    for qV in (0.0, 0.3):
+        sys_ = NEGFE(F, S, g_dev, ne=2 * 9, spin='r', T=T, Eminf=Eminf)
+        sys_.setIntegralLimits(N1=N1, N2=N2, Nnegf=Nn, tol=1e-4, Emin=Emin)
+        sys_.setVoltage(qV, fermi=mu)
+        sys_.Nnegf = Nn                                  # setVoltage resets the bias grid to its default of 50
+        EList, occ = sys_.FockToP()
+        assert rel_fro(sys_.P, ref_P(mu + qV / 2, mu - qV / 2)) < TOL, qV
+        assert np.all(np.diff(EList) >= 0) and len(occ) == N
+        assert abs(np.sum(occ) - np.real(np.trace(S @ sys_.P))) < 1e-9      # Lowdin occupations sum to Tr(S P)
+
+    # Fermi search on: the returned level reproduces the electron target (restricted: ne/2 per spin)
+    sys_ = NEGFE(F, S, g_dev, ne=2 * 9, spin='r', T=0.0, Eminf=Eminf)
+    sys_.setIntegralLimits(N1=64, N2=N2, tol=1e-4, Emin=Emin)
+    sys_.setVoltage(0.0, fermiMethod='muller')
+    assert sys_.updFermi
+    sys_.FockToP()
+    assert abs(np.real(np.trace(S @ sys_.P)) - 9.0) < 5e-3
+    with pytest.raises(NotImplementedError):
+        sys_.fermiMethod = 'predict'
+        sys_.FockToP()
+
+    # a model SCF loop: Fock = F0 + U * diag(P) (a Hubbard-like mean field) converges under damping
+    F0 = F.copy()
+    sys_ = NEGFE(F0, S, g_dev, ne=18, spin='r', T=T, Eminf=Eminf,
+                 fock_builder=lambda P: F0 + 0.3 * np.diag(np.real(np.diag(P))))
+    sys_.setIntegralLimits(N1=N1, N2=N2, tol=1e-4, Emin=Emin)
+    sys_.setVoltage(0.0, fermi=mu)
+    hist = sys_.SCF(conv=1e-6, damping=0.5, maxcycles=40)
+    assert hist and hist[-1] < 1e-6
+
+
 def test_full_size_properties_C2(engine):
     """BASELINE config C2 (N=200, constant Sigma, 1000 energies): size-independent
     properties instead of a 1000-point oracle run."""
