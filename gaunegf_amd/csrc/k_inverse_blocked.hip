@@ -644,7 +644,7 @@ int gj_pick(int n)
 
 
 // ======================================================================================
-// Large matrices (n > 512): the same in-place, implicit-pivot Gauss-Jordan reduction,
+// Large matrices (384 <= n <= 8192): the same in-place, implicit-pivot Gauss-Jordan reduction,
 // blocked at TWO levels across kernels.  For each window of WIN = 64 columns:
 //   gj_window_kernel  (one workgroup per matrix): factors the n x 64 block column in
 //       sub-panels of NBI columns with the register-strip pivot steps above and applies
@@ -923,6 +923,7 @@ int gj_large_pick(int n)
     if (n <= PT * 2) return 1;           // <= 1024: sub-panel 8, 2 rows per thread
     if (n <= PT * 4) return 2;           // <= 2048: sub-panel 8, 4 rows per thread
     if (n <= PT * 8) return 3;           // <= 4096: sub-panel 4, 8 rows per thread
+    if (n <= PT * 16) return 5;          // <= 8192: sub-panel 2, 16 rows per thread
     return 0;
 }
 
@@ -951,6 +952,7 @@ bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, siz
     case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info); return true;
     case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info); return true;
     case 4: gj_large_launch<8, 1>(st, n, nb, A, B, stride, piv, info); return true;
+    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info); return true;
     default: return false;
     }
 }

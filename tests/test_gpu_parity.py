@@ -121,11 +121,12 @@ def test_api_assertions_and_edges(engine):
         GrLessInt(F, S, g_dev, E, w, 5)
 
 
-def test_largest_window_configuration(engine):
-    """n > 2048 runs the windowed path with 8 rows per lane and sub-panels of 4 columns; one energy,
-    checked through the residual G A = I (an oracle inverse of this size costs seconds of CPU)."""
+@pytest.mark.parametrize("N", [2100, 4200])
+def test_largest_window_configurations(engine, N):
+    """n > 2048 runs the windowed path with 8 rows per lane and sub-panels of 4 columns, n > 4096 with
+    16 rows per lane and sub-panels of 2; one energy, checked through the residual G A = I (an oracle
+    inverse of this size costs seconds of CPU)."""
     from gaunegf_amd.integrate import GrBatch
-    N = 2100
     F, S, g_dev, g_ref = _const_provider(N, 77, nc=30)
     E = np.array([0.4 + 0.05j])
     G = GrBatch(F, S, g_dev, E)[0]
