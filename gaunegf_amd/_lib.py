@@ -56,6 +56,7 @@ SIGNATURES = {
     "negf_transmission_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "negf_sync": (C.c_int, [_vp]),
     "negf_last_info": (C.c_int, [_vp, C.c_int, _vp]),
+    "negf_last_iters": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "negf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "negf_profile_reset": (C.c_int, [_vp]),
     "negf_profile_read": (C.c_int, [_vp, C.c_char_p, _dp, _ip]),

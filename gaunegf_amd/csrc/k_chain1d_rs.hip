@@ -1,0 +1,597 @@
+// 1-D chain contact self-energy ("decimation") for n_c <= 64, register-stationary version.
+// gauNEGF/surfG1D.py:223-295 (g), :344-373 (sigma).  gfx950.
+//
+// One workgroup (256 threads, 4 waves) per (energy, contact); SEVERAL workgroups per CU.  The fixed
+// point is a chain of ~2000 dependent sweeps per workgroup, each a chain of 50 dependent pivot
+// steps, so one workgroup can never fill a CU: the kernel is built to be small enough that three
+// (n_c <= 57) or two workgroups share a CU and cover each other's latency chains.  That means ONE
+// n x n work matrix in LDS per workgroup (40.8 KB at n_c = 50) and <= 168 VGPRs:
+//   * B = (E + i eta) Sb - b is not stored per workgroup at all: wave w needs only row tile w of B, as
+//     the A operand of T = B g (wave w owns row tile w of T) and, conjugated, as the B operand of
+//     M = A - T B^H (wave w owns column tile w of M); it streams those 16 x n elements from the lead
+//     matrices Sb, b (shared by all workgroups of the contact, L2-resident) a few k-steps ahead.
+//   * the iterate g is kept twice: in the work matrix at the start of a sweep (B operand of T = B g;
+//     overwritten by T, then M) and as the "old" g of the mixing step, which each lane writes and
+//     reads back for its own 16 elements only: in a second LDS matrix when two workgroups share
+//     the CU, in a lane-private global scratch record (L2-resident) when three do.
+//   * the in-place Gauss-Jordan inverse of M works on column tiles OWNED by one wave per stage:
+//     the owner reads the pivot rows it needs (the Q fragment of its column tile) into registers
+//     before it writes, so no snapshot buffer and ONE workgroup barrier per 16-column panel.
+//     Panel s+1 is factored (one wave, lane = row, DPP arg-max, pivot row through v_readlane, no
+//     LDS traffic or barrier inside) while the other waves apply panel s; the factoring wave
+//     rotates with the panel so that the SIMDs share that load.
+// Per sweep
+//     T     = B g ;  M = A - T B^H          2 complex GEMMs on the FP64 matrix cores
+//     g_new = inv(M)                         blocked Gauss-Jordan, partial pivoting (izamax rule)
+//     diff  = max |g_new - g| / max(|g_new|, 1e-12) ;  g = r g_new + (1-r) g
+// Rows are never swapped: g_new[i][j] = W[pivrow[i]][colof[j]] is resolved when g_new is read.
+// The stopping rule only needs "diff > conv" / "diff <= conv"; both are evaluated on the squares
+// (|d|^2 > conv^2 max(|g_new|^2, 1e-24)), which is the same predicate without sqrt and divide.
+//
+// Every workgroup stops on ITS OWN convergence (the reference's vmap runs all energies until the
+// slowest lane converges; results are identical because a converged lane is frozen there).
+#include "negf_common.h"
+#include "wave_utils.h"
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = 4;
+constexpr int RS_NB = 16;                // panel width of the small inverse = one column tile
+
+struct ChainRsArgs {
+    const cplx *alpha, *Salpha, *beta, *Sbeta, *tau, *Stau;   // concatenated per contact
+    const int* nc;
+    const int* blk_off;
+    int n_contacts, blk_stride;
+    double eta, conv, relFactor;
+    int max_iter, force_iters;
+    cplx* gold;                      // [workgroups][KS][256] lane-private copies of the iterate (GOLD_GLOBAL kernels)
+    unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
+};
+
+template <int CTRL>
+__device__ __forceinline__ unsigned long long rs_dpp_max_key(unsigned long long k)
+{
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > k ? o : k;
+}
+
+// maximum of a 64-bit key over the wave (all lanes active), wave-uniform result
+__device__ __forceinline__ unsigned long long rs_wave_max_key(unsigned long long k)
+{
+    k = rs_dpp_max_key<0xB1>(k);      // quad_perm [1,0,3,2]
+    k = rs_dpp_max_key<0x4E>(k);      // quad_perm [2,3,0,1]
+    k = rs_dpp_max_key<0x141>(k);     // row_half_mirror
+    k = rs_dpp_max_key<0x140>(k);     // row_mirror
+    unsigned long long best = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, r * 16);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), r * 16);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    return best;
+}
+
+// Hide a loop-invariant value from the optimiser: without this LLVM hoists every (tile, k-step)
+// LDS address of the sweep out of the fixed-point loop -- hundreds of live address registers that
+// are then spilled to scratch and reloaded inside the MFMA loops.
+template <class T>
+__device__ __forceinline__ T rs_opaque(T v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ double rs_readlane_f64(double v, int srclane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srclane),
+                            __builtin_amdgcn_readlane(__double2loint(v), srclane));
+}
+
+// ---- panel [p0, p0+pw) factored by ONE wave: lane = row, 16 complex per lane; no barrier and no LDS
+// traffic inside: the pivot search is a DPP max of a packed 64-bit key, the pivot row is spread to
+// all lanes through v_readlane (the row index is wave-uniform).  A pivot row is not scaled at its
+// column step (multiplier 0, a one in the pivot column) but once at the end of the panel: the later
+// steps act linearly on it, and every lane runs the same select-free update.
+template <int P>
+__device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colof, int p0, int pw, int lane)
+{
+    const int r = rs_opaque(lane);                      // (see rs_opaque: nothing derived from the lane index is
+    cplx a[RS_NB];                                      //  hoisted out of the fixed-point loop and kept alive)
+    bool avail = r < n && colof[r] < 0;
+    cplx myip = cmake(1.0, 0.0);
+    cplx* wrow = W + r * P + p0;                        // rows >= n are zero padding
+#pragma unroll
+    for (int s = 0; s < RS_NB; ++s) {
+        const cplx v = wrow[s];
+        const bool ok = (r < n) & (s < pw);
+        a[s] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < RS_NB; ++j) {
+        if (j < pw) {
+            // key: upper 48 bits of |a|_1 over (0xFFFF - row): larger value, then lower row; 0 = none
+            const double v = cabs1(a[j]);
+            unsigned long long key = 0;
+            if (avail && v == v)
+                key = ((unsigned long long)__double_as_longlong(v) & ~0xFFFFull) | (unsigned long long)(0xFFFF - r);
+            key = rs_wave_max_key(key);
+            int pphys;
+            if (key != 0) {
+                pphys = 0xFFFF - (int)(key & 0xFFFFull);
+            } else {                                    // NaN column: lowest available row
+                int cand = avail ? r : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
+                pphys = cand;
+            }
+            pphys = __builtin_amdgcn_readfirstlane(pphys);
+            if (r == pphys) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
+            const cplx pv = cmake(rs_readlane_f64(a[j].x, pphys), rs_readlane_f64(a[j].y, pphys));
+            const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+            const cplx ip = cmake(pv.x * sc, -pv.y * sc);
+            const bool is_piv = r == pphys;
+            const cplx mf = cneg(cmul(a[j], ip));
+            const cplx coef = cmake(is_piv ? 0.0 : mf.x, is_piv ? 0.0 : mf.y);
+            // rank-1 update in two halves of 8 columns: 32 SGPRs of pivot-row values live at a time
+#pragma unroll
+            for (int h = 0; h < RS_NB; h += 8) {
+                cplx rb[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) rb[s] = cmake(rs_readlane_f64(a[h + s].x, pphys), rs_readlane_f64(a[h + s].y, pphys));
+#pragma unroll
+                for (int s = 0; s < 8; ++s) a[h + s] = cfma(a[h + s], coef, rb[s]);
+            }
+            a[j] = is_piv ? cmake(1.0, 0.0) : coef;
+            myip = cmake(is_piv ? ip.x : myip.x, is_piv ? ip.y : myip.y);
+            avail = avail && !is_piv;
+        }
+    }
+    if (r < n) {
+#pragma unroll
+        for (int s = 0; s < RS_NB; ++s)
+            if (s < pw) wrow[s] = cmul(a[s], myip);       // the deferred pivot-row scaling
+    }
+}
+
+// ---- trailing update of column tile tj with panel [p0, p0+pw), in place, by the wave that owns the
+// column tile in this stage:   W[i][col] = (i pivot row of the panel ? 0 : W[i][col]) + P[i][:] Q[:][col]
+// The Q fragment (the panel's pivot rows in this column tile) is read into registers before the first
+// store, so the owner needs no snapshot of the pivot rows.
+template <int T16, int P, int NKS>
+__device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow, const int* colof,
+                                              int tj, int p0, int pw, int lane)
+{
+    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+    const int col = tj * 16 + fi;
+    cplx qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int k = ks * 4 + fk;
+        const cplx v = W[pivrow[p0 + k] * P + col];          // k >= pw: some valid row, zeroed below
+        const bool ok = k < pw;
+        qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
+    }
+    cplx* cbase = W + fk * P + col;                          // C tile element (ti*16 + fk + 4r, col)
+    const cplx* pbase = W + fi * P + p0 + fk;                // P operand element (ti*16 + fi, p0 + ks*4 + fk)
+    const int* cfb = colof + fk;
+    // the operands of row tile ti+1 are requested before tile ti is stored (LDS operations of a wave
+    // execute in order, and tile ti+1 shares no element with tile ti), so that the loads overlap the MFMAs
+    cplx cv[2][4], pa[2][NKS];
+    int cf[2][4];
+    auto fetch = [&](int ti, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cf[s][r] = cfb[ti * 16 + 4 * r]; cv[s][r] = cbase[(ti * 16 + 4 * r) * P]; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) pa[s][ks] = pbase[ti * 16 * P + ks * 4];   // k >= pw pairs with qf == 0 (finite element)
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int ti = 0; ti < T16; ++ti) {
+        const int s = ti & 1;
+        if (ti + 1 < T16) fetch(ti + 1, s ^ 1);
+        d4 accr, acci;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool keep = !(cf[s][r] >= p0 && cf[s][r] < p0 + pw);
+            accr[r] = keep ? cv[s][r].x : 0.0; acci[r] = keep ? cv[s][r].y : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) zmfma(accr, acci, pa[s][ks], qf[ks]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + fk + 4 * r;
+            if (i < n && col < n) cbase[(ti * 16 + 4 * r) * P] = cmake(accr[r], acci[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// In-place blocked Gauss-Jordan reduction of the n x n matrix W (LDS, pitch P) with implicit
+// pivoting.  On return  inv[i][j] = W[pivrow[i]][colof[j]].  All 256 threads call it; colof[] must be
+// -1 and visible (a barrier since it was reset).  One barrier per stage: at stage s the wave that
+// factors panel s+1 first applies panel s to that column tile, then factors it, while the other waves
+// apply panel s to the remaining column tiles (one owner per column tile).
+template <int T16, int P>
+__device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, int tid,
+                                           unsigned long long* st = nullptr)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    int sti = 0;
+    auto stamp = [&]() __attribute__((always_inline)) { if (st && tid == 0) st[sti] = __builtin_amdgcn_s_memrealtime(); ++sti; };
+    const int npanels = (n + RS_NB - 1) / RS_NB;
+    for (int sgi = -1; sgi < npanels; ++sgi) {
+        const bool has_cur = sgi >= 0, has_next = sgi + 1 < npanels;
+        const int p0 = has_cur ? sgi * RS_NB : 0, pw = has_cur ? min(RS_NB, n - p0) : 0;
+        const int n0 = (sgi + 1) * RS_NB, nw = has_next ? min(RS_NB, n - n0) : 0;
+        const int fw = (sgi + 1) & (RS_WAVES - 1);              // the wave that factors panel sgi+1
+        if (has_cur) {
+            // column tiles other than the panel's own, one owner each: tile sgi+1 goes to the wave that
+            // factors it next, the others are dealt to the remaining waves (all four after the last panel)
+            const int team = has_next ? RS_WAVES - 1 : RS_WAVES;
+            const int me = has_next ? ((wave - fw - 1) & (RS_WAVES - 1)) : wave;
+            int cnt = 0;
+#pragma unroll 1
+            for (int tj = 0; tj < npanels; ++tj) {
+                if (tj == sgi) continue;
+                bool mine;
+                if (has_next && tj == sgi + 1) mine = wave == fw;
+                else { mine = (!has_next || wave != fw) && (cnt % team == me); ++cnt; }
+                if (mine) {
+                    // a narrow last panel (<= 4 columns) runs one k-step instead of four
+                    if (pw <= 4) rs_update_col<T16, P, 1>(n, W, pivrow, colof, tj, p0, pw, lane);
+                    else rs_update_col<T16, P, RS_NB / 4>(n, W, pivrow, colof, tj, p0, pw, lane);
+                }
+            }
+        }
+        if (has_next && wave == fw) {
+            if (st && lane == 0) st[16 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
+            rs_factor<P>(n, W, pivrow, colof, n0, nw, lane);
+            if (st && lane == 0) st[17 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
+        }
+        stamp();
+        __syncthreads();                 // panel sgi+1 (columns of W, pivrow/colof) and the update complete
+    }
+}
+
+// P: compile-time pitch of the work matrix (odd, >= n): every tile / k-step offset is an immediate of the
+// DS instruction, a lane needs ONE address register per operand stream.  The matrix has 16*T16 + 1 rows
+// of which rows >= n (and the columns >= n of a row) stay zero: operands of the padded tiles are read
+// without clamps or selects and are finite.
+template <int P, int OCC, bool GOLD_GLOBAL>
+__global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
+    ChainRsArgs a, const cplx* __restrict__ E, cplx* __restrict__ blk, int* __restrict__ iters,
+    int* __restrict__ converged)
+{
+    constexpr int T16 = (P - 1 + 15) / 16;              // 16-row tiles per dimension
+    constexpr int KS = (P + 3) / 4 < 4 * T16 ? (P + 3) / 4 : 4 * T16;   // k-steps of a full-width product (n <= P)
+    constexpr int ROWS = 16 * T16 + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int flags[2 * RS_WAVES];                 // per wave: any(diff > conv), all(diff <= conv)
+    __shared__ int pivrow[64], colof[64];
+
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int n = a.nc[c];
+    const int off = a.blk_off[c];
+    cplx* Ws = reinterpret_cast<cplx*>(smem_raw);       // [ROWS][P]: g (start of a sweep), T, M, the reduced M
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fk = lane >> 4;
+    const int ksteps = (n + 3) >> 2;
+    // the old iterate, element (ks*4 + fk, wave*16 + fi) of g at slot ks of this lane
+    // (global: [slot][thread], coalesced; LDS: a compact n x n matrix behind the work matrix)
+    cplx* gold0 = GOLD_GLOBAL ? a.gold + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KS) * RS_THREADS + tid
+                             : Ws + ROWS * P + fk * n + wave * 16 + fi;
+    const int gstride = GOLD_GLOBAL ? RS_THREADS : 4 * n;
+
+    const cplx* alpha = a.alpha + off; const cplx* Salpha = a.Salpha + off;
+    const cplx* beta = a.beta + off;   const cplx* Sbeta = a.Sbeta + off;
+    const cplx* tau = a.tau + off;     const cplx* Stau = a.Stau + off;
+    const cplx e = E[b];
+    const cplx z = cmake(e.x, e.y + a.eta);
+    const double conv2 = a.conv * a.conv, rf = a.relFactor, rf1 = 1.0 - a.relFactor;
+    auto sel = [](bool ok, cplx v) { return cmake(ok ? v.x : 0.0, ok ? v.y : 0.0); };
+    // A = (E + i eta) Sa - a at (i, j); global loads at clamped (always valid) indices
+    auto Aat = [&](int i, int j) {
+        const int o = min(i, n - 1) * n + min(j, n - 1);
+        return csub(cmul(z, Salpha[o]), alpha[o]);
+    };
+
+    // ---- the stationary operand of the two products: row tile `wave` of  zz * Smat - mat  in the MFMA
+    // A-operand layout, element (wave*16 + fi, ks*4 + fk).  It is NOT kept in registers across the sweep
+    // (52-64 VGPRs that the three-workgroups-per-CU budget does not have): each product streams it from the
+    // lead matrices, which every workgroup of the contact shares (L2 / L1 resident), PF k-steps ahead.
+    // Rows >= n give garbage in output rows / columns >= n only (never stored); k >= n is zeroed.
+    constexpr int PF = 3;
+    const cplx* opS = Sbeta; const cplx* opM = beta; cplx opz = z;
+    struct Stream { cplx s[PF], m[PF]; };
+    auto stream_fetch = [&](Stream& q, const cplx* sS, const cplx* sM, int ks, int fk) __attribute__((always_inline)) {
+        const int kc = min(ks * 4 + fk, n - 1);
+        q.s[ks % PF] = sS[kc]; q.m[ks % PF] = sM[kc];
+    };
+    auto stream_elem = [&](const Stream& q, int ks, int fk) __attribute__((always_inline)) {
+        return sel(ks * 4 + fk < n, csub(cmul(opz, q.s[ks % PF]), q.m[ks % PF]));
+    };
+
+    // wave w: acc[tj] = sum_k Op[w*16 + fi][k] * Ws[k][tj*16 + fi]  (row tile w of  Op Ws).  The padding of
+    // Ws is zero / finite, output columns >= n are never stored.
+    auto gemm_rowtile = [&](d4 (&accr)[T16], d4 (&acci)[T16]) __attribute__((always_inline)) {
+        const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+        const cplx* bb = Ws + fk * P + fi;
+        const int irow = min(wave * 16 + fi, n - 1) * n;
+        const cplx* sS = opS + irow; const cplx* sM = opM + irow;
+        Stream q;
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) stream_fetch(q, sS, sM, ks, fk);
+#pragma unroll
+        for (int tj = 0; tj < T16; ++tj) { accr[tj] = (d4){0, 0, 0, 0}; acci[tj] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                const cplx pa = stream_elem(q, ks, fk);
+                if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
+                cplx qb[T16];
+#pragma unroll
+                for (int tj = 0; tj < T16; ++tj) qb[tj] = bb[ks * 4 * P + tj * 16];
+#pragma unroll
+                for (int tj = 0; tj < T16; ++tj) zmfma(accr[tj], acci[tj], pa, qb[tj]);
+            }
+            // the LDS operands of the next k-step are not requested earlier than this: the register file
+            // holds the accumulators and ONE set of streamed operands; the other workgroups of the CU
+            // cover the LDS latency
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // wave w: acc[ti] = sum_k Ws[ti*16 + fi][k] * conj(Op[w*16 + fi][k])  (column tile w of  Ws Op^H)
+    auto gemm_coltile = [&](d4 (&accr)[T16], d4 (&acci)[T16]) __attribute__((always_inline)) {
+        const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+        const cplx* ab = Ws + fi * P + fk;
+        const int irow = min(wave * 16 + fi, n - 1) * n;
+        const cplx* sS = opS + irow; const cplx* sM = opM + irow;
+        Stream q;
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) stream_fetch(q, sS, sM, ks, fk);
+#pragma unroll
+        for (int ti = 0; ti < T16; ++ti) { accr[ti] = (d4){0, 0, 0, 0}; acci[ti] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                const cplx br = stream_elem(q, ks, fk);
+                if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
+                cplx pa[T16];
+#pragma unroll
+                for (int ti = 0; ti < T16; ++ti) pa[ti] = ab[ti * 16 * P + ks * 4];
+                // pa * conj(b)
+#pragma unroll
+                for (int ti = 0; ti < T16; ++ti) {
+                    accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].x, br.x, accr[ti], 0, 0, 0);
+                    accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.y, accr[ti], 0, 0, 0);
+                    acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.x, acci[ti], 0, 0, 0);
+                    acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ti].x, br.y, acci[ti], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // store row tile `wave` held as accumulators (C layout: rows fk + 4r, column fi of tile tj)
+    auto store_rowtile = [&](const d4 (&accr)[T16], const d4 (&acci)[T16]) __attribute__((always_inline)) {
+        const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+        cplx* cb = Ws + (wave * 16 + fk) * P + fi;
+#pragma unroll
+        for (int tj = 0; tj < T16; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = wave * 16 + fk + 4 * r, j = tj * 16 + fi;
+                if (i < n && j < n) cb[4 * r * P + tj * 16] = cmake(accr[tj][r], acci[tj][r]);
+            }
+    };
+    // g_new[k][col] = W[pivrow[k]][colof[col]] for this lane's elements; first: g = g_new, else the
+    // reference's mixing and stopping test (surfG1D.py:276-284).  Leaves g in Ws and in gold.
+    int over = 1, allok = 0;
+    auto gather_mix = [&](bool first) __attribute__((always_inline)) {
+        const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+        const int col = wave * 16 + fi;
+        const cplx* gsrc = Ws + colof[min(col, n - 1)];
+        const int* pvr = pivrow + fk;
+        cplx* gdst = Ws + fk * P + col;
+        cplx* gold = rs_opaque(gold0);
+        bool lane_over = false, lane_ok = true;
+        cplx gm[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 4 + fk;
+            gm[ks] = cmake(0.0, 0.0);
+            if (ks < ksteps && k < n && col < n) {
+                const cplx gn = gsrc[pvr[ks * 4] * P];
+                if (first) {
+                    gm[ks] = gn;
+                } else {
+                    const cplx go = gold[ks * gstride];
+                    const double dx = gn.x - go.x, dy = gn.y - go.y;
+                    const double num2 = dx * dx + dy * dy;
+                    const double den2 = fmax(gn.x * gn.x + gn.y * gn.y, 1e-24);
+                    lane_over |= num2 > conv2 * den2;
+                    lane_ok &= num2 <= conv2 * den2;
+                    gm[ks] = cmake(gn.x * rf + go.x * rf1, gn.y * rf + go.y * rf1);
+                }
+                gold[ks * gstride] = gm[ks];
+            }
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four gathers in flight, not sixteen
+        }
+        if (!first) {
+            const bool w_over = __ballot(lane_over) != 0ull;
+            const bool w_ok = __ballot(!lane_ok) == 0ull;
+            if (lane == 0) { flags[wave] = w_over ? 1 : 0; flags[RS_WAVES + wave] = w_ok ? 1 : 0; }
+        }
+        __syncthreads();                                // all gathers done: Ws may be overwritten
+        if (tid < 64) colof[tid] = -1;                  // for the next inverse (every lane has read its colof)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 4 + fk;
+            if (ks < ksteps && k < n && col < n) gdst[ks * 4 * P] = gm[ks];
+        }
+        if (!first) {
+            over = flags[0] | flags[1] | flags[2] | flags[3];
+            allok = flags[4] & flags[5] & flags[6] & flags[7];
+        }
+        __syncthreads();
+    };
+
+    // ---- g0 = inv(A); the padding of the work matrix is zeroed once and never written again
+    for (int t = tid; t < ROWS * P; t += RS_THREADS) {
+        const int i = t / P, j = t - i * P;
+        Ws[t] = sel(i < n && j < n, Aat(i, j));
+    }
+    if (tid < 64) { colof[tid] = -1; pivrow[tid] = 0; }
+    __syncthreads();
+
+    // One copy of every phase in the instruction stream (the loop body has to stay inside the 64 KB
+    // instruction cache two CUs share): the start g0 = inv(A) is the first pass through the inverse, and
+    // Sigma = t g t^H (t = E Stau - tau, no eta) runs as a last pass through the two products with t in
+    // place of B:  X = t g (row tiles) -> Ws,  Sigma = X t^H (column tiles) -> global.
+    int count = 0;
+    bool first = true, final_pass = false;
+    while (true) {
+        unsigned long long* st = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && count == 10) ? a.stamps : nullptr;
+        if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+        rs_inverse<T16, P>(n, Ws, pivrow, colof, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
+        if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+        gather_mix(first);
+        if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+        if (!first) ++count;
+        first = false;
+        if (a.force_iters >= 0 ? count >= a.force_iters : !(over && count < a.max_iter)) {
+            final_pass = true;
+            opS = Stau; opM = tau; opz = e;
+        }
+        d4 mr[T16], mi[T16];
+        // T = B g : row tile `wave`; g is read from Ws by every wave, so T waits in registers
+        gemm_rowtile(mr, mi);
+        __syncthreads();
+        store_rowtile(mr, mi);
+        __syncthreads();
+        if (st && tid == 0) st[3] = __builtin_amdgcn_s_memrealtime();
+        // T B^H : column tile `wave`
+        gemm_coltile(mr, mi);
+        const int fis = rs_opaque(lane & 15), fks = rs_opaque(lane >> 4), j = wave * 16 + fis;
+        if (final_pass) {
+            cplx* out = blk + (size_t)b * a.blk_stride + off;
+#pragma unroll
+            for (int ti = 0; ti < T16; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ti * 16 + fks + 4 * r;
+                    if (i < n && j < n) out[i * n + j] = cmake(mr[ti][r], mi[ti][r]);
+                }
+            break;
+        }
+        __syncthreads();
+        // M = A - T B^H
+        cplx* mb = Ws + fks * P + j;
+#pragma unroll
+        for (int ti = 0; ti < T16; ++ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fks + 4 * r;
+                const cplx av = Aat(i, j);
+                if (i < n && j < n) mb[(ti * 16 + 4 * r) * P] = cmake(av.x - mr[ti][r], av.y - mi[ti][r]);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // the A elements of one tile in flight, not of all
+        }
+        __syncthreads();
+        if (st && tid == 0) st[4] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (tid == 0) {
+        if (iters) iters[(size_t)b * a.n_contacts + c] = count;
+        if (converged) converged[(size_t)b * a.n_contacts + c] = (count > 0 && allok) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+bool chain1d_lds_supported(int nc_max) { return nc_max <= 64; }
+
+size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb)
+{
+    return (size_t)4 * ((nc_max + 15) >> 4) * RS_THREADS * n_contacts * nb;     // >= KS slots per lane
+}
+
+namespace {
+
+template <int P>
+void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts, int nb, const cplx* E, cplx* blk,
+                       int* iters, int* conv, cplx* gold_scratch, int occ_env)
+{
+    constexpr int T16 = (P - 1 + 15) / 16;
+    const size_t wmat = (size_t)(16 * T16 + 1) * P * sizeof(cplx);
+    const size_t gold_lds = (size_t)n_max * n_max * sizeof(cplx);
+    // occupancy from the LDS share of a workgroup (+ < 1 KB of static LDS): the work matrix alone when the
+    // old iterate goes to global scratch, both matrices otherwise
+    auto fits = [](size_t smem, int per_cu) { return (smem + 768) * per_cu <= 160 * 1024; };
+    auto launch = [&](auto kern, size_t smem) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(n_contacts, nb), dim3(RS_THREADS), smem, st, a, E, blk, iters, conv);
+    };
+    constexpr int OCC_MAX = T16 <= 2 ? 4 : 3;          // register budget: 128 VGPRs (T16 <= 2), 168 above
+    if (occ_env != 2 && fits(wmat + gold_lds, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, false>, wmat + gold_lds);
+    else if (occ_env != 2 && gold_scratch && fits(wmat, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, true>, wmat);
+    else if (fits(wmat + gold_lds, 2) || !gold_scratch) launch(chain1d_rs_kernel<P, 2, false>, wmat + gold_lds);
+    else launch(chain1d_rs_kernel<P, 2, true>, wmat);
+}
+
+}  // namespace
+
+void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
+                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch)
+{
+    ChainRsArgs a;
+    a.alpha = p.d_alpha; a.Salpha = p.d_Salpha; a.beta = p.d_beta; a.Sbeta = p.d_Sbeta;
+    a.tau = p.d_tau; a.Stau = p.d_Stau;
+    a.nc = d_nc; a.blk_off = d_blk_off;
+    a.n_contacts = p.n_contacts; a.blk_stride = p.blk_stride;
+    a.eta = p.eta; a.conv = p.conv; a.relFactor = p.relFactor;
+    a.max_iter = p.max_iter; a.force_iters = p.force_iters;
+    a.gold = gold_scratch;
+    static unsigned long long* d_stamps = nullptr;
+    static int want_stamps = -1;
+    if (want_stamps < 0) {
+        want_stamps = getenv("NEGF_CHAIN_STAMPS") ? 1 : 0;
+        if (want_stamps) { (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 64 * sizeof(unsigned long long)); }
+    }
+    a.stamps = d_stamps;
+    static int occ_env = -1;
+    if (occ_env < 0) { const char* e = getenv("NEGF_CHAIN1D_OCC"); occ_env = e ? atoi(e) : 0; }
+    // one instantiation per pitch class of the largest contact (smaller contacts of the same launch run
+    // in the same padded matrix): the smallest odd pitch of the list that holds n_max columns
+    const int n = p.nc_max;
+#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env)
+    if (n <= 16) RS_CASE(17);
+    else if (n <= 25) RS_CASE(25);
+    else if (n <= 32) RS_CASE(33);
+    else if (n <= 41) RS_CASE(41);
+    else if (n <= 48) RS_CASE(49);
+    else if (n <= 51) RS_CASE(51);
+    else if (n <= 57) RS_CASE(57);
+    else RS_CASE(65);
+#undef RS_CASE
+    if (d_stamps) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[64];
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        if (h[0]) {
+            auto us = [&](int i) { return h[i] ? (double)(h[i] - h[0]) / 100.0 : -1.0; };
+            fprintf(stderr, "[chain stamps] sweep 10 (us): inverse %.2f  diff+mix %.2f  T=Bg %.2f  M=A-TB^H %.2f  (total %.2f) | inverse stages:",
+                    us(1), us(2) - us(1), us(3) - us(2), us(4) - us(3), us(4));
+            for (int i = 8; i < 16 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) / 100.0);
+            fprintf(stderr, " | factor begin-end:");
+            for (int i = 24; i < 34 && h[i]; i += 2) fprintf(stderr, " %.2f-%.2f", (double)(h[i] - h[0]) / 100.0, (double)(h[i + 1] - h[0]) / 100.0);
+            fprintf(stderr, "\n");
+        }
+    }
+}

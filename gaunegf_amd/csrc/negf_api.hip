@@ -204,7 +204,15 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
         static int force_v1 = -1;
         if (force_v1 < 0) { const char* e = getenv("NEGF_CHAIN1D_ALGO"); force_v1 = (e && strcmp(e, "global") == 0) ? 1 : 0; }
         if (chain1d_lds_supported(p->nc_max) && !force_v1) {
-            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv);
+            const size_t need = chain1d_lds_scratch_elems(p->nc_max, p->n_contacts, nb);
+            if (need > c->scratch_cap) {
+                NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+                dev_free(c->d_scratch); c->scratch_cap = 0;
+                int rc = dev_alloc(&c->d_scratch, need);
+                if (rc) return rc;
+                c->scratch_cap = need;
+            }
+            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch);
             return NEGF_OK;
         }
         const size_t per = chain1d_scratch_per_wg(p->nc_max);
@@ -894,6 +902,22 @@ int negf_last_info(negf_ctx* c, int m, int* info)
 {
     if (!c || !info || m < 0 || m > c->m_cap) return NEGF_EINVAL;
     return download(c, info, c->d_info, (size_t)m);
+}
+
+int negf_last_iters(negf_ctx* c, int handle, int m, int* iters, int* converged)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    if (!c || !p || m < 0 || m > c->m_cap) return NEGF_EINVAL;
+    const size_t cnt = (size_t)m * p->n_contacts;
+    if (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) {
+        if (p->n_contacts > c->contacts_cap) return NEGF_EINVAL;
+        int rc;
+        if (iters && (rc = download(c, iters, c->d_iters, cnt))) return rc;
+        if (converged && (rc = download(c, converged, c->d_conv, cnt))) return rc;
+    } else {
+        for (size_t i = 0; i < cnt; ++i) { if (iters) iters[i] = 0; if (converged) converged[i] = 1; }
+    }
+    return NEGF_OK;
 }
 
 // --------------------------------------------------------------- host variants

@@ -218,10 +218,13 @@ void launch_chain1d(hipStream_t st, const SigmaProvider& p, const int* d_nc, con
                     int nb, const cplx* E, cplx* blk, int* iters, int* conv, cplx* scratch,
                     size_t scratch_per_wg);
 size_t chain1d_scratch_per_wg(int nc_max);
-// LDS-resident MFMA version for n_c <= 64 (k_chain1d_lds.hip)
+// register-stationary MFMA version for n_c <= 64 (k_chain1d_rs.hip)
 bool chain1d_lds_supported(int nc_max);
+// gold_scratch: chain1d_lds_scratch_elems() complex values of lane-private scratch (may be null:
+// the kernel then keeps the old iterate in LDS at a lower occupancy)
+size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb);
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
-                        const cplx* E, cplx* blk, int* iters, int* conv);
+                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch);
 
 // Bethe lattice: one workgroup per (energy, contact); writes per-atom 9x9 blocks
 void launch_bethe(hipStream_t st, const SigmaProvider& p, int nb, const cplx* E, cplx* blk,

@@ -297,6 +297,13 @@ class Engine:
         check(self._lib.negf_last_info(self._ctx, int(m), _ptr(info)), "negf_last_info")
         return info[:m]
 
+    def last_iters_dev(self, handle, m, n_contacts):
+        """(sweeps, converged) [m, n_contacts] of the fixed points run by the last call."""
+        it = np.zeros((max(m, 1), max(n_contacts, 1)), dtype=np.int32)
+        cv = np.zeros((max(m, 1), max(n_contacts, 1)), dtype=np.int32)
+        check(self._lib.negf_last_iters(self._ctx, int(handle), int(m), _ptr(it), _ptr(cv)), "negf_last_iters")
+        return it[:m], cv[:m]
+
     # ---------------------------------------------------------- diagnostics
     def profile(self, on=True):
         check(self._lib.negf_profile_enable(self._ctx, 1 if on else 0), "negf_profile_enable")

@@ -181,6 +181,10 @@ int negf_transmission_dev(negf_ctx* ctx, int handle, int contact_L, int contact_
                           double* T_dev, double* Tspin_dev);
 int negf_sync(negf_ctx* ctx);
 int negf_last_info(negf_ctx* ctx, int m, int* info);
+/* sweeps / converged flags of the self-energy fixed points run by the last call
+ * ([m][n_contacts] each; the counts the reference's lax.while_loop state carries,
+ * surfG1D.py:271-288, surfGBethe.py:1004-1022); zeros / ones for providers without a loop */
+int negf_last_iters(negf_ctx* ctx, int handle, int m, int* iters, int* converged);
 
 /* ------------------------------------------------------------- diagnostics */
 /* hipEvent timing of the library's own kernels, per kernel family

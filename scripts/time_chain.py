@@ -3,7 +3,7 @@ import sys, time, numpy as np
 sys.path.insert(0, '/root/repo')
 from scripts.bench_configs import _c3_system
 F, S, g, ref = _c3_system()
-E = np.linspace(-2, 2, 256)
+E = np.linspace(-2, 2, int(sys.argv[1]) if len(sys.argv) > 1 else 384)
 g.sigma_batch(E[:8])
 t0 = time.perf_counter(); sig, it, cv = g.sigma_batch(E); t = time.perf_counter() - t0
-print(f"256 energies x 2 contacts: {t*1e3:.1f} ms, mean sweeps {it.mean():.0f}, {t/2/it.mean()*1e6*256/256:.1f} us per sweep-round (2 rounds of 256 workgroups)")
+print(f"{len(E)} energies x 2 contacts: {t*1e3:.1f} ms, mean sweeps {it.mean():.0f}, {it.sum()/t/1e6:.2f} M sweeps/s")

@@ -365,9 +365,11 @@ def test_compact_gamma_products_match_dense_and_oracle(engine):
             assert abs(T[0][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
 
 
-@pytest.mark.parametrize("nc", [4, 10, 20])
+@pytest.mark.parametrize("nc", [4, 10, 20, 33, 48, 50, 64, 65, 80])
 def test_chain1d_fixed_trip_count(engine, nc):
-    """Same number of sweeps on both sides -> the iterate itself must agree."""
+    """Same number of sweeps on both sides -> the iterate itself must agree.  n_c = 33/48 and 50/64
+    are the three- and four-tile LDS kernels (50 = BASELINE C3's lead, 64 with B outside LDS),
+    65 and 80 the global-scratch kernel for n_c > 64."""
     N = 3 * nc
     F, S, g_dev, g_ref = _chain_system(N, nc, 70 + nc, 1e-4)
     g_dev.force_iters = 40; g_ref.force_iters = 40
@@ -397,6 +399,42 @@ def test_chain1d_free_running(engine):
     from gaunegf_amd.integrate import GrInt
     w = np.ones_like(E) * (E[1] - E[0])
     assert rel_fro(GrInt(F, S, g_dev, E, w), oracle.GrInt(F, S, g_ref, E, w)) < 1e-3
+
+
+@pytest.mark.parametrize("nc,eta", [(50, 1e-4), (64, 1e-3), (72, 1e-3)])
+def test_chain1d_free_running_large_leads(engine, nc, eta):
+    """The reference's stopping rule (surfG1D.py:271-288) at BASELINE C3's lead size and at the two
+    kernel boundaries: iteration counts within +-1 (also at the 2000 cap), Sigma within 10*conv."""
+    F, S, g_dev, g_ref = _chain_system(2 * nc + 20, nc, 5 + nc, eta)
+    E = np.array([-1.7, -0.4, 0.9, 0.2 + 0.3j])
+    sig, iters, conv = g_dev.sigma_batch(E)
+    for k, e in enumerate(E):
+        ref = g_ref.sigmaTot(e)
+        for c in (0, 1):
+            cnt, dlast = g_ref.last_iters[(complex(e), c)][:2]
+            assert abs(int(iters[k, c]) - cnt) <= 1, (nc, e, c, int(iters[k, c]), cnt)
+        assert rel_fro(sig[k], ref) < 10 * 1e-5, (nc, e)
+
+
+def test_chain1d_forced_global_kernel(engine, monkeypatch):
+    """NEGF_CHAIN1D_ALGO=global sends a small lead through the n_c > 64 kernel too: both kernels
+    must give the same iterate as the oracle."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import oracle
+        from test_gpu_parity import _chain_system
+        from helpers import rel_fro
+        F, S, g_dev, g_ref = _chain_system(60, 20, 90, 1e-4)
+        g_dev.force_iters = 40; g_ref.force_iters = 40
+        for E in (0.3, 0.1 + 0.2j):
+            assert rel_fro(g_dev.sigmaTot(E), g_ref.sigmaTot(E)) < 1e-10
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__))
+    env = dict(os.environ, NEGF_CHAIN1D_ALGO="global")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_chain1d_integrals_fixed_trip(engine):
@@ -648,3 +686,84 @@ def test_full_size_properties_C2(engine):
     # bounded oracle sample of the integral itself
     sub = slice(0, M, 25)
     assert rel_fro(GrInt(F, S, g_dev, E[sub], w[sub]), oracle.GrInt(F, S, g_ref, E[sub], w[sub])) < TOL
+
+
+# --------------------------------------------------------------------------- #
+# BASELINE.json configs C3 / C4 / C5 at their real matrix sizes (bounded energy samples:
+# the oracle costs seconds per point at these sizes)
+# --------------------------------------------------------------------------- #
+def test_config_C3_shape(engine):
+    """C3: N=500 device, 1-D chain leads n_c=50, eta=1e-4 (examples/SiNEGF.py:44), a 16-point sample of
+    the 2000-point Legendre grid on [-2,2] eV; fixed trip count -> identical Sigma(E) -> 1e-8 on GrInt,
+    GrLessInt and the per-energy G."""
+    from gaunegf_amd.integrate import GrInt, GrLessInt, GrBatch
+    F, S, g_dev, g_ref = _chain_system(500, 50, 3, 1e-4)
+    g_dev.force_iters = 50; g_ref.force_iters = 50
+    E, w = oracle.real_axis_grid(-2.0, 2.0, 2000, 0.0)
+    sub = np.arange(7, 2000, 125)
+    assert len(sub) == 16
+    ref = oracle.GrInt(F, S, g_ref, E[sub], w[sub])
+    assert rel_fro(GrInt(F, S, g_dev, E[sub], w[sub]), ref) < TOL
+    assert rel_fro(GrLessInt(F, S, g_dev, E[sub[:4]], w[sub[:4]], -1),
+                   oracle.GrLessInt(F, S, g_ref, E[sub[:4]], w[sub[:4]], -1)) < TOL
+    G = GrBatch(F, S, g_dev, E[sub[:2]])
+    for k in range(2):
+        assert rel_fro(G[k], oracle.gr_point(g_ref.sigmaTot(E[sub[k]]), E[sub[k]], F, S)) < TOL
+
+
+def test_config_C4_shape(engine):
+    """C4: N=800, Bethe-lattice Sigma (Au.bethe), 2 contacts x 3 atoms x 9 orbitals; 3 points of the
+    486-point ANT contour and 2 of the 256-point real-axis grid, fixed trip count."""
+    from gaunegf_amd.surfGBethe import surfGB
+    from gaunegf_amd.integrate import GrInt
+    N = 800
+    F, S = random_system(N, 4)
+    coords, orbMap, orbTyp = _bethe_device("Au", N)
+    lat = os.path.join(os.path.dirname(__file__), "golden", "Au")
+    g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
+    g.force_iters = 30
+    Xi = g.Xi if g.Sdict['sss'] == 0 else None
+
+    class Ref:
+        def sigma(self, E, i, conv=None):
+            at = g.gList[i]
+            return oracle.bethe_contact_sigma(E, N, g.indsLists[i], g.nIndLists[i], at.H, at.Slist, at.Vlist,
+                                              1e-6, Xi=Xi, force_iters=30)
+        def sigmaTot(self, E, conv=None): return self.sigma(E, 0) + self.sigma(E, 1)
+    E, w = oracle.contour_grid(-8.0, 0.0, 486, 0.0)
+    sub = np.array([0, 243, 485])
+    assert rel_fro(GrInt(F, S, g, E[sub], w[sub]), oracle.GrInt(F, S, Ref(), E[sub], w[sub])) < TOL
+    Er, wr = oracle.real_axis_grid(-1e6, -8.0, 256, 0.0)
+    sub = np.array([3, 250])
+    assert rel_fro(GrInt(F, S, g, Er[sub], wr[sub]), oracle.GrInt(F, S, Ref(), Er[sub], wr[sub])) < TOL
+
+
+def test_config_C5_shape(engine):
+    """C5: spin-polarised 2 x 1000 block F/S (scf.py:177-180 layout), constant Sigma expanded with
+    kron(I2, sigma) (transport.py:100), two energies of the qV = 0.5 V window at T = 300 K:
+    GrLessInt(ind=-1) and the spin-'u' block transmission."""
+    from gaunegf_amd.integrate import GrLessInt
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+    N, nc = 1000, 30
+    Fa, Sa = random_system(N, 5); Fb, _ = random_system(N, 6)
+    Z = np.zeros((N, N))
+    F = np.block([[Fa, Z], [Z, Fb]]); S = np.kron(np.eye(2), Sa)
+    inds, s1, s2 = const_sigma_pair(N, Sa, nc)
+    sig = [np.kron(np.eye(2), s1), np.kron(np.eye(2), s2)]
+
+    class G:
+        def sigma(self, E, i): return sig[i]
+        def sigmaTot(self, E): return sig[0] + sig[1]
+    E, w = oracle.bias_window_grid(-0.25, 0.25, 512, 300.0)
+    sub = np.array([100, 400])
+    from gaunegf_amd.surfGTester import surfGTest
+    got = GrLessInt(F, S, G(), E[sub], w[sub], -1)
+    assert rel_fro(got, oracle.GrLessInt(F, S, G(), E[sub], w[sub], -1)) < TOL
+    sc = SigmaCalculator(s1, s2)
+    Et = np.array([-0.1, 0.2])
+    T, Ts = calculate_transmission(F, S, sc, Et, spin='u')
+    g1 = np.kron(np.eye(2), 1j * (s1 - s1.conj().T)); g2 = np.kron(np.eye(2), 1j * (s2 - s2.conj().T))
+    for k, e in enumerate(Et):
+        tot, comp = oracle.transmission_spin_block(e, F, S, sig[0] + sig[1], g1, g2)
+        assert np.max(np.abs(Ts[k] - comp)) < TOL * max(1.0, np.max(np.abs(comp)))
+        assert abs(T[k] - tot) < TOL * max(1.0, abs(tot))
