@@ -50,32 +50,25 @@ struct ChainRsArgs {
     unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
 };
 
+// maximum of a 32-bit key over the wave (all lanes active), wave-uniform result: four DPP steps inside
+// the rows of 16 lanes (v_max_u32 with a DPP source), then the four row results through v_readlane
 template <int CTRL>
-__device__ __forceinline__ unsigned long long rs_dpp_max_key(unsigned long long k)
+__device__ __forceinline__ unsigned rs_dpp_max_u32(unsigned k)
 {
-    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, 0xF, 0xF, false);
     return o > k ? o : k;
 }
 
-// maximum of a 64-bit key over the wave (all lanes active), wave-uniform result
-__device__ __forceinline__ unsigned long long rs_wave_max_key(unsigned long long k)
+__device__ __forceinline__ unsigned rs_wave_max_u32(unsigned k)
 {
-    k = rs_dpp_max_key<0xB1>(k);      // quad_perm [1,0,3,2]
-    k = rs_dpp_max_key<0x4E>(k);      // quad_perm [2,3,0,1]
-    k = rs_dpp_max_key<0x141>(k);     // row_half_mirror
-    k = rs_dpp_max_key<0x140>(k);     // row_mirror
-    unsigned long long best = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, r * 16);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), r * 16);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        best = o > best ? o : best;
-    }
-    return best;
+    k = rs_dpp_max_u32<0xB1>(k);      // quad_perm [1,0,3,2]
+    k = rs_dpp_max_u32<0x4E>(k);      // quad_perm [2,3,0,1]
+    k = rs_dpp_max_u32<0x141>(k);     // row_half_mirror
+    k = rs_dpp_max_u32<0x140>(k);     // row_mirror
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)k, 0), b = (unsigned)__builtin_amdgcn_readlane((int)k, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)k, 32), d = (unsigned)__builtin_amdgcn_readlane((int)k, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 // Hide a loop-invariant value from the optimiser: without this LLVM hoists every (tile, k-step)
@@ -94,13 +87,22 @@ __device__ __forceinline__ double rs_readlane_f64(double v, int srclane)
                             __builtin_amdgcn_readlane(__double2loint(v), srclane));
 }
 
-// ---- panel [p0, p0+pw) factored by ONE wave: lane = row, 16 complex per lane; no barrier and no LDS
-// traffic inside: the pivot search is a DPP max of a packed 64-bit key, the pivot row is spread to
-// all lanes through v_readlane (the row index is wave-uniform).  A pivot row is not scaled at its
-// column step (multiplier 0, a one in the pivot column) but once at the end of the panel: the later
-// steps act linearly on it, and every lane runs the same select-free update.
+// ---- panel [p0, p0+pw) factored by ONE wave: lane = row, 16 complex per lane, no barrier inside.  A wave
+// alone issues one instruction per ~4 cycles whatever its kind, and the vector ALU of its SIMD is what
+// the co-resident workgroups compete for, so the column step is written for instruction count:
+//   * pivot search: |re|+|im| (izamax metric) compared on the HIGH WORD of the double -- sign 0, exponent,
+//     20 mantissa bits -- with one v_max_u32 per DPP step; the pivot is the lowest row whose high word
+//     equals the maximum (ballot + find-first): the LAPACK choice up to ties within 2^-20 relative, which
+//     go to the lower row as LAPACK's exact ties do;
+//   * the pivot row reaches the other lanes through a 256-byte LDS line (the pivot lane writes its 16
+//     values, every lane reads them back: 32 LDS instructions instead of 68 v_readlane, and off the VALU);
+//   * 1/|pivot|^2 by v_rcp_f64 and two Newton steps (the pivots of these matrices are far from the
+//     overflow / denormal range the IEEE division sequence guards).
+// A pivot row is not scaled at its column step (multiplier 0, a one in the pivot column) but once at
+// the end of the panel: the later steps act linearly on it, and every lane runs the same select-free update.
 template <int P>
-__device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colof, int p0, int pw, int lane)
+__device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colof, cplx* rowline /*[16] LDS*/,
+                                          int p0, int pw, int lane)
 {
     const int r = rs_opaque(lane);                      // (see rs_opaque: nothing derived from the lane index is
     cplx a[RS_NB];                                      //  hoisted out of the fixed-point loop and kept alive)
@@ -116,38 +118,43 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
 #pragma unroll
     for (int j = 0; j < RS_NB; ++j) {
         if (j < pw) {
-            // key: upper 48 bits of |a|_1 over (0xFFFF - row): larger value, then lower row; 0 = none
             const double v = cabs1(a[j]);
-            unsigned long long key = 0;
-            if (avail && v == v)
-                key = ((unsigned long long)__double_as_longlong(v) & ~0xFFFFull) | (unsigned long long)(0xFFFF - r);
-            key = rs_wave_max_key(key);
+            const unsigned hi = (avail && v == v) ? (unsigned)__double2hiint(v) : 0u;
+            const unsigned m = rs_wave_max_u32(hi);
             int pphys;
-            if (key != 0) {
-                pphys = 0xFFFF - (int)(key & 0xFFFFull);
-            } else {                                    // NaN column: lowest available row
-                int cand = avail ? r : 0x7fffffff;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
-                pphys = cand;
+            if (m != 0) {
+                pphys = (int)__ffsll((unsigned long long)__ballot(hi == m)) - 1;
+            } else {                                    // no usable candidate (zero / NaN column): lowest available row
+                const unsigned long long av = __ballot(avail);
+                pphys = av ? (int)__ffsll(av) - 1 : 0x7fffffff;
             }
             pphys = __builtin_amdgcn_readfirstlane(pphys);
-            if (r == pphys) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
-            const cplx pv = cmake(rs_readlane_f64(a[j].x, pphys), rs_readlane_f64(a[j].y, pphys));
-            const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
-            const cplx ip = cmake(pv.x * sc, -pv.y * sc);
             const bool is_piv = r == pphys;
+            cplx rb[RS_NB];
+            // one lane writes, all lanes read: the wave-level barriers keep the compiler from ordering the
+            // two sides of the divergent branch the other way round (it does, without them), the LDS then
+            // executes the wave's instructions in order
+            __builtin_amdgcn_wave_barrier();            // the reads of the previous column step are issued
+            if (is_piv) {
+                pivrow[p0 + j] = pphys; colof[pphys] = p0 + j;
+#pragma unroll
+                for (int s = 0; s < RS_NB; ++s) rowline[s] = a[s];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int s = 0; s < RS_NB; ++s) rb[s] = rowline[s];
+            const cplx pv = rb[j];
+            const double d = pv.x * pv.x + pv.y * pv.y;
+            double sc = __builtin_amdgcn_rcp(d);
+            sc = fma(sc, fma(-d, sc, 1.0), sc);
+            sc = fma(sc, fma(-d, sc, 1.0), sc);
+            const cplx ip = cmake(pv.x * sc, -pv.y * sc);
             const cplx mf = cneg(cmul(a[j], ip));
             const cplx coef = cmake(is_piv ? 0.0 : mf.x, is_piv ? 0.0 : mf.y);
-            // rank-1 update in two halves of 8 columns: 32 SGPRs of pivot-row values live at a time
 #pragma unroll
-            for (int h = 0; h < RS_NB; h += 8) {
-                cplx rb[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) rb[s] = cmake(rs_readlane_f64(a[h + s].x, pphys), rs_readlane_f64(a[h + s].y, pphys));
-#pragma unroll
-                for (int s = 0; s < 8; ++s) a[h + s] = cfma(a[h + s], coef, rb[s]);
-            }
+            for (int s = 0; s < RS_NB; ++s) a[s] = cfma(a[s], coef, rb[s]);
             a[j] = is_piv ? cmake(1.0, 0.0) : coef;
             myip = cmake(is_piv ? ip.x : myip.x, is_piv ? ip.y : myip.y);
             avail = avail && !is_piv;
@@ -219,7 +226,7 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
 // factors panel s+1 first applies panel s to that column tile, then factors it, while the other waves
 // apply panel s to the remaining column tiles (one owner per column tile).
 template <int T16, int P>
-__device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, int tid,
+__device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, cplx* rowline, int tid,
                                            unsigned long long* st = nullptr)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -252,7 +259,7 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
         }
         if (has_next && wave == fw) {
             if (st && lane == 0) st[16 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
-            rs_factor<P>(n, W, pivrow, colof, n0, nw, lane);
+            rs_factor<P>(n, W, pivrow, colof, rowline, n0, nw, lane);
             if (st && lane == 0) st[17 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
         }
         stamp();
@@ -261,7 +268,7 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
 }
 
 // P: compile-time pitch of the work matrix (odd, >= n): every tile / k-step offset is an immediate of the
-// DS instruction, a lane needs ONE address register per operand stream.  The matrix has 16*T16 + 1 rows
+// DS instruction, a lane needs ONE address register per operand stream.  The matrix has 16*T16 rows
 // of which rows >= n (and the columns >= n of a row) stay zero: operands of the padded tiles are read
 // without clamps or selects and are finite.
 template <int P, int OCC, bool GOLD_GLOBAL>
@@ -271,22 +278,23 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
 {
     constexpr int T16 = (P - 1 + 15) / 16;              // 16-row tiles per dimension
     constexpr int KS = (P + 3) / 4 < 4 * T16 ? (P + 3) / 4 : 4 * T16;   // k-steps of a full-width product (n <= P)
-    constexpr int ROWS = 16 * T16 + 1;
+    constexpr int WELEMS = 16 * T16 * P + 16;           // 16*T16 rows and a few elements of slack behind the last one
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ int flags[2 * RS_WAVES];                 // per wave: any(diff > conv), all(diff <= conv)
     __shared__ int pivrow[64], colof[64];
+    __shared__ cplx rowline[RS_NB];                     // pivot row of the column step being factored
 
     const int c = blockIdx.x, b = blockIdx.y;
     const int n = a.nc[c];
     const int off = a.blk_off[c];
-    cplx* Ws = reinterpret_cast<cplx*>(smem_raw);       // [ROWS][P]: g (start of a sweep), T, M, the reduced M
+    cplx* Ws = reinterpret_cast<cplx*>(smem_raw);       // [16*T16][P] (+ slack): g (start of a sweep), T, M, the reduced M
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fk = lane >> 4;
     const int ksteps = (n + 3) >> 2;
     // the old iterate, element (ks*4 + fk, wave*16 + fi) of g at slot ks of this lane
     // (global: [slot][thread], coalesced; LDS: a compact n x n matrix behind the work matrix)
     cplx* gold0 = GOLD_GLOBAL ? a.gold + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KS) * RS_THREADS + tid
-                             : Ws + ROWS * P + fk * n + wave * 16 + fi;
+                             : Ws + WELEMS + fk * n + wave * 16 + fi;
     const int gstride = GOLD_GLOBAL ? RS_THREADS : 4 * n;
 
     const cplx* alpha = a.alpha + off; const cplx* Salpha = a.Salpha + off;
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     };
 
     // ---- g0 = inv(A); the padding of the work matrix is zeroed once and never written again
-    for (int t = tid; t < ROWS * P; t += RS_THREADS) {
+    for (int t = tid; t < WELEMS; t += RS_THREADS) {
         const int i = t / P, j = t - i * P;
         Ws[t] = sel(i < n && j < n, Aat(i, j));
     }
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     while (true) {
         unsigned long long* st = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && count == 10) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-        rs_inverse<T16, P>(n, Ws, pivrow, colof, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
+        rs_inverse<T16, P>(n, Ws, pivrow, colof, rowline, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
         if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
         gather_mix(first);
         if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
@@ -528,11 +536,12 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
                        int* iters, int* conv, cplx* gold_scratch, int occ_env)
 {
     constexpr int T16 = (P - 1 + 15) / 16;
-    const size_t wmat = (size_t)(16 * T16 + 1) * P * sizeof(cplx);
+    const size_t wmat = (size_t)(16 * T16 * P + 16) * sizeof(cplx);
     const size_t gold_lds = (size_t)n_max * n_max * sizeof(cplx);
     // occupancy from the LDS share of a workgroup (+ < 1 KB of static LDS): the work matrix alone when the
     // old iterate goes to global scratch, both matrices otherwise
-    auto fits = [](size_t smem, int per_cu) { return (smem + 768) * per_cu <= 160 * 1024; };
+    // (allocated in granules of 1280 bytes: 53.8 KB per workgroup is the most that still fits three times)
+    auto fits = [](size_t smem, int per_cu) { return ((smem + 832 + 1279) / 1280) * 1280 * per_cu <= 160 * 1024; };
     auto launch = [&](auto kern, size_t smem) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             (void)hipGetLastError();
@@ -571,6 +580,9 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     // in the same padded matrix): the smallest odd pitch of the list that holds n_max columns
     const int n = p.nc_max;
 #define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env)
+#ifdef RS_FAST_BUILD
+    if (n <= 16) RS_CASE(17); else RS_CASE(51);
+#else
     if (n <= 16) RS_CASE(17);
     else if (n <= 25) RS_CASE(25);
     else if (n <= 32) RS_CASE(33);
@@ -579,6 +591,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     else if (n <= 51) RS_CASE(51);
     else if (n <= 57) RS_CASE(57);
     else RS_CASE(65);
+#endif
 #undef RS_CASE
     if (d_stamps) {
         (void)hipStreamSynchronize(st);
