@@ -2,30 +2,42 @@
 """
 bench.py -- energy-points/sec of the NEGF hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): synthetic random Hermitian F / S with
-N_orb = 200, energy-independent contacts (Gamma = 0.2 eV on 20 + 20 orbitals plus
--i 1e-9 S everywhere, matTools.formSigma), 1000 Gauss-Legendre energy points on
-[-3, 3] eV PER GPU (weak scaling: rank r owns the points r, r+W, ... of a W*1000
-point grid).  One "step" = one GrInt pass over the local shard: for every energy
-assemble E S - F - Sigma, invert (complex128, partial pivoting), accumulate w G --
-followed, for N > 1, by ONE RCCL sum all-reduce of the N_orb x N_orb result.
-F, S, Sigma, the energy grid and the weights are resident in HBM before the timed
-region; the result stays in HBM.
+N = 1 runs in this process.  N > 1: when launched by torch.distributed.run (RANK/WORLD_SIZE in the
+environment) every rank runs the worker below; launched plainly, this process starts N workers
+through torch.distributed.run as CHILD processes before it has touched the GPU, and passes their
+output through.
+
+Headline workload (BASELINE.json configs[2], "C3" -- the largest single-GPU configuration):
+synthetic random Hermitian F / S with N_orb = 500 whose two leads are 1-D chains with a
+50-orbital unit cell (surfG1D decimation self-energy, eta = 1e-4 as examples/SiNEGF.py:44), 2000
+Gauss-Legendre energy points on [-2, 2] eV PER GPU (weak scaling: rank r owns the points r, r+W, ...
+of a W*2000 point grid).  One "step" = one GrInt pass over the local shard: for every energy run
+the two decimation fixed points to the reference's stopping rule (surfG1D.py:271-288: conv 1e-5,
+relaxation 0.1, at most 2000 sweeps), form Sigma = t g t^H, assemble E S - F - Sigma, invert
+(complex128, partial pivoting), accumulate w G -- followed, for N > 1, by ONE RCCL sum all-reduce of
+the N_orb x N_orb result.  F, S, the lead matrices, the energy grid and the weights are resident in
+HBM before the timed region; the result stays in HBM.
 
 The JSON line carries
-  roofline     : the inverse kernel family vs the FP64 matrix-core peak.  achieved =
-                 8 N^3 flops per energy point x points per launch
-                 / average launch duration, timed with hipEvents recorded by the
-                 library on the stream the kernels run on, during the timed steps.
-  cpu_baseline : the numpy oracle (the reference's CPU restatement) timed on this
-                 host on a bounded sample of the same energies.
+  roofline     : the kernel that dominates the step (the chain fixed point, > 90 % of it) against the
+                 FP64 matrix-core peak.  achieved = algorithmic flops per launch / average launch
+                 duration; flops per (energy, contact) = (8 + 24 sweeps + 16) n_c^3 (start inverse, per
+                 sweep an inverse and two products, Sigma = t g t^H), with the
+                 sweep counts the kernel reports; durations from hipEvents recorded by the library on
+                 the stream the kernels run on, during the timed steps.
+  cpu_baseline : the numpy oracle (the reference's CPU restatement) timed on this host on a bounded
+                 sample of the same energies.
+  extra        : the north-star target case (N_orb = 500, constant Sigma, 1000 energies: GPU time and
+                 CPU sample) and BASELINE config C2 (N_orb = 200, constant Sigma, 1000 energies) with the
+                 roofline of the dense inverse kernels.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,113 +48,110 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense FP64 matrix peak (vector FP64 peak is the same)
-N_ORB = 200
-M_PER_GPU = 1000
-NC = 20
-SEED = 2
 
 
-def make_system(N, seed, nc):
+# ------------------------------------------------------------------ synthetic systems
+def random_system(N, seed):
     rng = np.random.default_rng(seed)
     A = rng.standard_normal((N, N))
     F = (A + A.T) * (1.0 / np.sqrt(2 * N)) * 2
     B = rng.standard_normal((N, N))
     S = np.eye(N) + 0.1 * (B + B.T) / np.sqrt(2 * N)
-    inds = [list(range(nc)), list(range(N - nc, N))]
-    return F, S, inds
+    return F, S
 
 
-def legendre_grid(M, lo=-3.0, hi=3.0):
+def chain_lead(nc, seed, scale_b=0.2):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((nc, nc)); alpha = (a + a.T) * 0.5 * 0.5
+    beta = rng.standard_normal((nc, nc)) * scale_b
+    s = rng.standard_normal((nc, nc)); Salpha = np.eye(nc) + 0.05 * (s + s.T) * 0.5 / np.sqrt(nc)
+    Sbeta = 0.05 * rng.standard_normal((nc, nc)) / np.sqrt(nc)
+    return alpha, Salpha, beta, Sbeta
+
+
+def c3_system(N=500, nc=50, eta=1e-4):
+    F, S = random_system(N, 3)
+    left = list(range(nc)); right = list(range(N - nc, N))
+    aL = chain_lead(nc, 31); aR = chain_lead(nc, 32)
+    kw = dict(taus=[aL[2].copy(), aR[2].copy()], staus=[aL[3].copy(), aR[3].copy()], alphas=[aL[0], aR[0]],
+              aOverlaps=[aL[1], aR[1]], betas=[aL[2], aR[2]], bOverlaps=[aL[3], aR[3]], eta=eta)
+    return F, S, [left, right], kw
+
+
+def legendre_grid(M, lo, hi):
     from scipy.special import roots_legendre
     x, w = roots_legendre(M)
     mid = (hi - lo) / 2
     return mid * (np.real(x) + 1) + lo, mid * w
 
 
-def cpu_baseline(F, S, inds, E, w, budget_s=12.0):
-    """Time the oracle's GrInt (plain numpy loop, solve(A, I)) on a bounded sample.
-
-    The BLAS thread count that is fastest for this matrix size on this host is used
-    (all cores is NOT the fastest for N ~ 200: oversubscription), so the baseline is the
-    best the reference's CPU path can do here; `cores` reports that thread count."""
-    import oracle
-    g = oracle.ConstSigma(F, S, inds, -0.1j)
-    ncpu = os.cpu_count() or 1
+# ------------------------------------------------------------------------------------ CPU legs
+def _blas_limits():
     try:
         from threadpoolctl import threadpool_limits
+        return threadpool_limits
     except Exception:
-        threadpool_limits = None
-    best_t, best_per = ncpu, None
-    by_threads = {}
-    cands = sorted({t for t in (1, 4, 8, 16, 32, 64, ncpu) if t <= ncpu}) if threadpool_limits else [ncpu]
+        return None
+
+
+def cpu_baseline(make_call, n_total, label, budget_s, probe_pts=2):
+    """Time `make_call(idx)` (an oracle integral over the energies idx) on a bounded sample.
+
+    The BLAS thread count that is fastest for this workload on this host is used (all cores is not
+    the fastest for these matrix sizes: oversubscription); `cores` reports that thread count."""
+    limits = _blas_limits()
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (1, 4, 16, ncpu) if t <= ncpu}) if limits else [ncpu]
+    probe_idx = np.linspace(0, n_total - 1, probe_pts).astype(int)
+    best_t, best_per, by_threads = ncpu, None, {}
     for t in cands:
-        ctx = threadpool_limits(limits=t) if threadpool_limits else None
+        ctx = limits(limits=t) if limits else None
         try:
-            oracle.GrInt(F, S, g, E[:2], w[:2])
-            t0 = time.perf_counter()
-            oracle.GrInt(F, S, g, E[:6], w[:6])
-            per = (time.perf_counter() - t0) / 6
+            t0 = time.perf_counter(); make_call(probe_idx); per = (time.perf_counter() - t0) / probe_pts
         finally:
             if ctx is not None:
                 ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
-        by_threads[str(t)] = round(1.0 / per, 2)
+        by_threads[str(t)] = round(1.0 / per, 3)
         if best_per is None or per < best_per:
             best_t, best_per = t, per
-    n = int(max(16, min(len(E), budget_s / max(best_per, 1e-6))))
-    idx = np.linspace(0, len(E) - 1, n).astype(int)
-    # a whole grid can take less than the ~10 s a stable CPU number needs: repeat the pass
-    passes = int(max(1, min(50, np.ceil(budget_s / max(n * best_per, 1e-6)))))
-    ctx = threadpool_limits(limits=best_t) if threadpool_limits else None
+    n = int(max(4, min(n_total, budget_s / max(best_per, 1e-6))))
+    idx = np.linspace(0, n_total - 1, n).astype(int)
+    ctx = limits(limits=best_t) if limits else None
     try:
-        t0 = time.perf_counter()
-        for _ in range(passes):
-            oracle.GrInt(F, S, g, E[idx], w[idx])
-        dt = time.perf_counter() - t0
+        t0 = time.perf_counter(); make_call(idx); dt = time.perf_counter() - t0
     finally:
         if ctx is not None:
             ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else ctx.unregister()
-    return {"value": n * passes / dt, "unit": "energy-points/s", "cores": int(best_t), "kind": "port",
-            "points_per_s_by_blas_threads": by_threads,      # 6-point probes; "1" is the scalar figure
-            "sample": f"{passes} x {n} of {len(E)} energies of the same N_orb={F.shape[0]} workload, numpy {np.__version__} "
-                      f"solve(A,I) loop (oracle.GrInt), best of BLAS threads {cands} = {best_t} "
-                      f"(host has {ncpu} logical CPUs), {dt:.2f} s"}
+    return {"value": n / dt, "unit": "energy-points/s", "cores": int(best_t), "kind": "port",
+            "points_per_s_by_blas_threads": by_threads,
+            "sample": f"{n} of {n_total} energies (evenly spaced, {100.0 * n / n_total:.1f} % of the grid) of {label}; "
+                      f"numpy {np.__version__} oracle loop (reference CPU restatement), best of BLAS threads {cands} "
+                      f"= {best_t} (host has {ncpu} logical CPUs), {dt:.1f} s"}
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per inverse launch from the committed PMC profile of this same command
-    (profiles/r01_pmc/..., separate --pmc passes): 2 x FETCH_SIZE (gfx950 reports half of a
-    wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc", "c2_bench_pmc_per_launch_avg.json")
+def pmc_traffic_bytes(kernel_substr, fname):
+    """HBM bytes per launch from a committed PMC profile (separate --pmc passes): 2 x FETCH_SIZE
+    (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE,
+    both in KiB."""
+    path = os.path.join(ROOT, "profiles", fname)
     try:
         data = json.load(open(path))
         for name, ctr in data.items():
-            if "gj_blocked_kernel" in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
+            if kernel_substr in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.join("profiles", fname)
     except Exception:
         pass
     return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--norb", type=int, default=N_ORB)
-    ap.add_argument("--energies", type=int, default=M_PER_GPU)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--extra", action="store_true", help="also time N_orb=500 (north-star target case)")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------- the worker
+def worker(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     # NEGF_BENCH_REHEARSAL=1: several ranks share the visible GPUs and talk over gloo -- a dry run
@@ -159,13 +168,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from gaunegf_amd.engine import Engine
-    from gaunegf_amd.matTools import formSigma
+    from gaunegf_amd.surfG1D import surfG
 
-    N, M = args.norb, args.energies
-    F, S, inds = make_system(N, SEED, NC)
-    sig = [formSigma(inds[0], -0.1j, N, S), formSigma(inds[1], -0.1j, N, S)]
+    N, NC, M, ETA = 500, 50, args.energies, 1e-4
+    F, S, inds, kw = c3_system(N, NC, ETA)
     # global grid of world*M points, cyclic shard (distributed.shard_indices)
-    Eg, wg = legendre_grid(M * world)
+    Eg, wg = legendre_grid(M * world, -2.0, 2.0)
     E_loc = np.ascontiguousarray(Eg[rank::world], dtype=np.complex128)
     w_loc = np.ascontiguousarray(wg[rank::world], dtype=np.complex128)
 
@@ -173,17 +181,21 @@ def main():
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     eng.set_system(F, S)
-    h = eng.sigma_const(sig)
+    lead = surfG(F, S, inds, **kw)
+    h = lead._negf_lower(eng)
     dev = torch.device("cuda", local_rank)
-    E_dev = torch.view_as_complex(torch.from_numpy(E_loc.view(np.float64).reshape(-1, 2).copy())).to(dev)
-    w_dev = torch.view_as_complex(torch.from_numpy(w_loc.view(np.float64).reshape(-1, 2).copy())).to(dev)
+    to_dev = lambda a: torch.view_as_complex(torch.from_numpy(a.view(np.float64).reshape(-1, 2).copy())).to(dev)
+    E_dev, w_dev = to_dev(E_loc), to_dev(w_loc)
     out = torch.zeros((N, N), dtype=torch.complex128, device=dev)
     out_real = torch.view_as_real(out)
 
     def step():
         eng.gr_int_dev(h, M, E_dev.data_ptr(), w_dev.data_ptr(), out.data_ptr())
         if world > 1:
-            dist.all_reduce(out_real, op=dist.ReduceOp.SUM)
+            if rehearsal:
+                t = out_real.cpu(); dist.all_reduce(t, op=dist.ReduceOp.SUM); out_real.copy_(t)
+            else:
+                dist.all_reduce(out_real, op=dist.ReduceOp.SUM)
 
     def fence():
         if world > 1:
@@ -201,28 +213,31 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    inv_ms, inv_launches = eng.profile_read("inverse")
-    asm_ms, _ = eng.profile_read("assemble")
-    acc_ms, _ = eng.profile_read("accumulate")
+    prof = {k: eng.profile_read(k) for k in ("chain1d", "inverse", "assemble", "accumulate")}
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # sanity: the all-reduced result equals the sum over the global grid on rank 0's view
     info = eng.last_info_dev(M)
     assert not np.any(info), "singular pivot reported"
+    iters, conv = eng.last_iters_dev(h, M, 2)
     res = out.cpu().numpy()
     assert np.all(np.isfinite(res))
 
     if rank == 0:
         pts = args.steps * M * world
-        flops_per_launch_pt = 8.0 * N ** 3
-        launches = max(inv_launches, 1)
-        pts_per_launch = args.steps * M / launches
-        avg_launch_ms = inv_ms / launches
-        achieved = flops_per_launch_pt * pts_per_launch / (avg_launch_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
+        ch_ms, ch_launches = prof["chain1d"]
+        inv_ms, inv_launches = prof["inverse"]
+        ch_launches = max(ch_launches, 1); inv_launches = max(inv_launches, 1)
+        sweeps_per_step = float(iters.sum())                           # this rank's shard, one pass
+        flops_chain_step = float(np.sum(8.0 + 24.0 * iters + 16.0)) * NC ** 3
+        launches_per_step = ch_launches / args.steps
+        avg_chain_ms = ch_ms / ch_launches
+        achieved = flops_chain_step / launches_per_step / (avg_chain_ms * 1e-3) / 1e12 if ch_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic_bytes("chain1d", "r02_pmc_c3_per_launch_avg.json")
+        inv_tf = 8.0 * N ** 3 * M * args.steps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
         line = {
             "metric": "energy-points/sec (complex128 G(E) solves)",
             "value": pts / dt,
@@ -236,52 +251,118 @@ def main():
             "vs_baseline": None,
             "dtype": "f64 (complex128)",
             "data": "synthetic",
-            "config": {"workload": f"C2: N_orb={N}, constant Sigma (Gamma=0.2 eV, n_c={NC}/side), "
-                                   f"{M} Gauss-Legendre energies per GPU on [-3,3] eV, GrInt",
-                       "n_orb": N, "energies_per_gpu": M, "sharding": f"energy-cyclic x{world}",
-                       "density_matrix_wall_ms": dt / args.steps * 1e3},
+            "config": {"workload": f"C3: N_orb={N} + surfG1D decimation self-energy (two 1-D chain leads, n_c={NC}, "
+                                   f"eta={ETA:g}, reference stopping rule), {M} Gauss-Legendre energies per GPU on "
+                                   f"[-2,2] eV, GrInt",
+                       "n_orb": N, "n_c": NC, "energies_per_gpu": M, "sharding": f"energy-cyclic x{world}",
+                       "density_matrix_wall_ms": dt / args.steps * 1e3,
+                       "sweeps_per_energy_and_contact_mean": float(iters.mean()),
+                       "fixed_points_converged_frac": float(conv.mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_bytes()[0], "traffic_source": pmc_traffic_bytes()[1],
-                         "algorithmic_bytes_per_launch": 2.0 * 16.0 * N * N * pts_per_launch,
-                         "kernel": "inverse (blocked Gauss-Jordan)",
-                         "avg_launch_ms": avg_launch_ms, "launches": launches,
-                         "flops_per_point": flops_per_launch_pt,
-                         "other_ms_per_step": {"assemble": asm_ms / args.steps, "accumulate": acc_ms / args.steps}},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "chain1d_rs_kernel (1-D chain decimation fixed point, one workgroup per energy and contact)",
+                         "avg_launch_ms": avg_chain_ms, "launches": ch_launches,
+                         "sweeps_per_launch": sweeps_per_step / launches_per_step,
+                         "flops_per_sweep": 24.0 * NC ** 3,
+                         "algorithmic_flops_per_launch": flops_chain_step / launches_per_step,
+                         # compulsory HBM bytes: the six lead matrices of both contacts once per launch (every
+                         # workgroup re-reads them from L2) + one n_c x n_c Sigma block written per unit
+                         "algorithmic_bytes_per_launch": 16.0 * NC * NC * 2 * (6 + M / launches_per_step),
+                         "share_of_step": ch_ms / args.steps / (dt / args.steps * 1e3),
+                         "other_ms_per_step": {"inverse": inv_ms / args.steps, "assemble": prof["assemble"][0] / args.steps,
+                                               "accumulate": prof["accumulate"][0] / args.steps},
+                         "inverse_kernels_tflops": inv_tf},
         }
         if not args.no_cpu and world == 1:           # the CPU leg is an N=1 figure (rank 0 only)
-            line["cpu_baseline"] = cpu_baseline(F, S, inds, np.real(E_loc), np.real(w_loc))
+            import oracle
+            ref = oracle.Chain1DSigma(F, S, inds, kw["taus"], kw["staus"], kw["alphas"], kw["aOverlaps"],
+                                      kw["betas"], kw["bOverlaps"], eta=ETA)
+            Er, wr = np.real(E_loc), np.real(w_loc)
+            line["cpu_baseline"] = cpu_baseline(lambda idx: oracle.GrInt(F, S, ref, Er[idx], wr[idx]), M,
+                                                f"the same C3 workload (N_orb={N}, n_c={NC} decimation, GrInt)",
+                                                budget_s=args.cpu_budget)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        if args.extra:
-            line["extra"] = extra_n500(eng, args)
+        if not args.no_extra and world == 1:
+            line["extra"] = {"north_star_N500_x_1000": extra_const(eng, 500, 50, 1000, 3, reps=3, cpu_budget=6.0,
+                                                                   no_cpu=args.no_cpu),
+                             "C2_N200_x_1000": extra_const(eng, 200, 20, 1000, 2, reps=10, cpu_budget=4.0,
+                                                           no_cpu=args.no_cpu)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def extra_n500(eng, args):
-    """North-star target case: N_orb=500, 1000 energies, density-matrix build vs CPU."""
+def extra_const(eng, N, nc, M, seed, reps, cpu_budget, no_cpu):
+    """Constant-Sigma GrInt (BASELINE C2 / the north-star sentence's N_orb=500 x 1000 case): device-resident
+    timing like the headline, roofline of the dense inverse kernels, CPU sample."""
     import torch
     from gaunegf_amd.matTools import formSigma
-    N, M = 500, 1000
-    F, S, inds = make_system(N, 3, 50)
+    F, S = random_system(N, seed)
+    inds = [list(range(nc)), list(range(N - nc, N))]
     sig = [formSigma(inds[0], -0.1j, N, S), formSigma(inds[1], -0.1j, N, S)]
-    E, w = legendre_grid(M)
+    lo, hi = (-3.0, 3.0)
+    E, w = legendre_grid(M, lo, hi)
     eng.set_system(F, S)
     h = eng.sigma_const(sig)
-    eng.gr_int(h, E, w)                 # warm-up with the whole grid: the 12 GB workspace is allocated here
+    dev = torch.device("cuda", eng.device)
+    to_dev = lambda a: torch.view_as_complex(torch.from_numpy(
+        np.ascontiguousarray(a, dtype=np.complex128).view(np.float64).reshape(-1, 2).copy())).to(dev)
+    E_dev, w_dev = to_dev(E), to_dev(w)
+    out = torch.zeros((N, N), dtype=torch.complex128, device=dev)
+    for _ in range(2):
+        eng.gr_int_dev(h, M, E_dev.data_ptr(), w_dev.data_ptr(), out.data_ptr())
     torch.cuda.synchronize()
-    dts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        eng.gr_int(h, E, w)
-        dts.append(time.perf_counter() - t0)
-    dt = sorted(dts)[1]
-    cpu = cpu_baseline(F, S, inds, E, w, budget_s=8.0)
-    return {"n_orb": N, "energies": M, "gpu_wall_s": dt, "gpu_points_per_s": M / dt,
-            "gpu_tflops": 8.0 * N ** 3 * M / dt / 1e12, "cpu_points_per_s": cpu["value"],
-            "cpu_sample": cpu["sample"], "speedup": (M / dt) / cpu["value"]}
+    eng.profile(True); eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.gr_int_dev(h, M, E_dev.data_ptr(), w_dev.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    inv_ms, inv_l = eng.profile_read("inverse")
+    eng.profile(False)
+    tf = 8.0 * N ** 3 * M * reps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
+    res = {"n_orb": N, "energies": M, "gpu_ms_per_density_matrix": dt * 1e3, "gpu_points_per_s": M / dt,
+           "inverse_ms_per_pass": inv_ms / reps, "inverse_tflops": tf, "inverse_frac_of_fp64_peak": tf / FP64_MFMA_PEAK_TFLOPS}
+    if not no_cpu:
+        import oracle
+        g = oracle.ConstSigma(F, S, inds, -0.1j)
+        cpu = cpu_baseline(lambda idx: oracle.GrInt(F, S, g, E[idx], w[idx]), M,
+                           f"the same N_orb={N} constant-Sigma workload", budget_s=cpu_budget, probe_pts=4)
+        res.update({"cpu_points_per_s": cpu["value"], "cpu_cores": cpu["cores"], "cpu_sample": cpu["sample"],
+                    "speedup": (M / dt) / cpu["value"]})
+    eng.sigma_free(h)
+    return res
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--energies", type=int, default=2000, help="energy points per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the N_orb=500 x 1000 and C2 secondary lines")
+    ap.add_argument("--cpu-budget", type=float, default=18.0, help="seconds of CPU work for the headline baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start the ranks as fresh child processes (nothing in this process has
+        # touched the GPU: torch is not even imported yet) and hand their exit code back
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    worker(args)
 
 
 if __name__ == "__main__":
