@@ -32,6 +32,7 @@
 // slowest lane converges; results are identical because a converged lane is frozen there).
 #include "negf_common.h"
 #include "wave_utils.h"
+#include <algorithm>
 
 namespace {
 
@@ -47,6 +48,7 @@ struct ChainRsArgs {
     double eta, conv, relFactor;
     int max_iter, force_iters;
     cplx* gold;                      // [workgroups][KS][256] lane-private copies of the iterate (GOLD_GLOBAL kernels)
+    int gold_lds_off, gold_lds_slots; // the first slots of a lane's copy live in LDS at this element offset
     unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
 };
 
@@ -293,9 +295,14 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     const int ksteps = (n + 3) >> 2;
     // the old iterate, element (ks*4 + fk, wave*16 + fi) of g at slot ks of this lane
     // (global: [slot][thread], coalesced; LDS: a compact n x n matrix behind the work matrix)
-    cplx* gold0 = GOLD_GLOBAL ? a.gold + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KS) * RS_THREADS + tid
-                             : Ws + WELEMS + fk * n + wave * 16 + fi;
-    const int gstride = GOLD_GLOBAL ? RS_THREADS : 4 * n;
+    // Slot ks < gold_lds_slots: LDS, a compact matrix (pitch n) at element gold_lds_off of the dynamic LDS --
+    // behind the work matrix when two workgroups share the CU; when three do, in the rows n_max+2 .. 16*T16-1
+    // of the work matrix itself, which only feed discarded output rows of the padded tiles and may hold any
+    // finite values.  The other slots: global scratch [slot][thread] (coalesced); with the LDS part taken
+    // off, the scratch of the workgroups of an XCD fits its 4 MB L2 and is rewritten there sweep after sweep.
+    cplx* gold_g = GOLD_GLOBAL ? a.gold + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KS) * RS_THREADS + tid : nullptr;
+    cplx* gold_l = Ws + a.gold_lds_off + fk * n + wave * 16 + fi;
+    const int lds_slots = GOLD_GLOBAL ? a.gold_lds_slots : KS;
 
     const cplx* alpha = a.alpha + off; const cplx* Salpha = a.Salpha + off;
     const cplx* beta = a.beta + off;   const cplx* Sbeta = a.Sbeta + off;
@@ -407,7 +414,8 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         const cplx* gsrc = Ws + colof[min(col, n - 1)];
         const int* pvr = pivrow + fk;
         cplx* gdst = Ws + fk * P + col;
-        cplx* gold = rs_opaque(gold0);
+        cplx* gl = rs_opaque(gold_l);
+        cplx* gg = GOLD_GLOBAL ? rs_opaque(gold_g) : nullptr;
         bool lane_over = false, lane_ok = true;
         cplx gm[KS];
 #pragma unroll
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                 if (first) {
                     gm[ks] = gn;
                 } else {
-                    const cplx go = gold[ks * gstride];
+                    const cplx go = (!GOLD_GLOBAL || ks < lds_slots) ? gl[ks * 4 * n] : gg[ks * RS_THREADS];
                     const double dx = gn.x - go.x, dy = gn.y - go.y;
                     const double num2 = dx * dx + dy * dy;
                     const double den2 = fmax(gn.x * gn.x + gn.y * gn.y, 1e-24);
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                     lane_ok &= num2 <= conv2 * den2;
                     gm[ks] = cmake(gn.x * rf + go.x * rf1, gn.y * rf + go.y * rf1);
                 }
-                gold[ks * gstride] = gm[ks];
+                if (!GOLD_GLOBAL || ks < lds_slots) gl[ks * 4 * n] = gm[ks]; else gg[ks * RS_THREADS] = gm[ks];
             }
             if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four gathers in flight, not sixteen
         }
@@ -542,10 +550,15 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
     // old iterate goes to global scratch, both matrices otherwise
     // (allocated in granules of 1280 bytes: 53.8 KB per workgroup is the most that still fits three times)
     auto fits = [](size_t smem, int per_cu) { return ((smem + 832 + 1279) / 1280) * 1280 * per_cu <= 160 * 1024; };
+    // old iterate behind the work matrix (all slots in LDS) ...
+    ChainRsArgs al = a; al.gold_lds_off = 16 * T16 * P + 16; al.gold_lds_slots = 1 << 20;
+    // ... or its first slots in the unused rows n_max+2 .. of the work matrix, the rest in global scratch
+    ChainRsArgs ag = a; ag.gold_lds_off = (n_max + 2) * P;
+    ag.gold_lds_slots = std::max(0, (16 * T16 * P + 16 - ag.gold_lds_off) / (4 * n_max));
     auto launch = [&](auto kern, size_t smem) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             (void)hipGetLastError();
-        hipLaunchKernelGGL(kern, dim3(n_contacts, nb), dim3(RS_THREADS), smem, st, a, E, blk, iters, conv);
+        hipLaunchKernelGGL(kern, dim3(n_contacts, nb), dim3(RS_THREADS), smem, st, smem > wmat ? al : ag, E, blk, iters, conv);
     };
     constexpr int OCC_MAX = T16 <= 2 ? 4 : 3;          // register budget: 128 VGPRs (T16 <= 2), 168 above
     if (occ_env != 2 && fits(wmat + gold_lds, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, false>, wmat + gold_lds);

@@ -111,8 +111,20 @@ __global__ __launch_bounds__(GJ_THREADS) void gj_unblocked_kernel(int n, cplx* _
     if (tid == 0) info[blockIdx.x] = bad;
 }
 
-void launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info)
+bool launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info)
 {
-    const size_t smem = (size_t)n * (2 * sizeof(cplx) + sizeof(int));
+    const size_t smem = (size_t)n * (2 * sizeof(cplx) + sizeof(int));       // pivot row, pivot column, ipiv
+    const size_t limit = 158 * 1024;
+    if (smem > limit) return false;                                          // n > 4494
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gj_unblocked_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
     hipLaunchKernelGGL(gj_unblocked_kernel, dim3(nb), dim3(GJ_THREADS), smem, st, n, A, info);
+    return true;
 }

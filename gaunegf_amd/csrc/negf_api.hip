@@ -163,10 +163,12 @@ SigmaProvider* get_provider(negf_ctx* c, int handle)
     return c->providers[handle];
 }
 
+// A handle is the provider's index in a table that only grows: a freed slot stays empty and is never
+// handed out again, so a stale handle (freed, or dropped by a change of the matrix dimension) can only
+// ever name an empty slot -- negf_* calls then return NEGF_EINVAL instead of running on another
+// object's self-energy.
 int add_provider(negf_ctx* c, SigmaProvider* p)
 {
-    for (size_t i = 0; i < c->providers.size(); ++i)
-        if (!c->providers[i]) { c->providers[i] = p; return (int)i; }
     c->providers.push_back(p);
     return (int)c->providers.size() - 1;
 }
@@ -182,18 +184,23 @@ int norm_contact(const SigmaProvider* p, int ind)
     return ind;
 }
 
-void run_inverse(negf_ctx* c, int nb, int* info)
+int run_inverse(negf_ctx* c, int nb, int* info)
 {
     ProfScope ps(c, "inverse");
     int algo = c->inverse_algo;
     if (algo == 0) algo = inverse_blocked_supported(c->n) ? 2 : 1;
-    if (algo == 2 && !inverse_blocked_supported(c->n)) algo = 1;
     bool in_b = false;
-    if (algo == 2) in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info);
-    else launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info);
+    if (algo == 2) {
+        // false: no blocked kernel serves this n (nothing was launched) -> the unblocked kernel
+        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info);
+        if (!in_b) algo = 1;
+    }
+    if (algo == 1 && !launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info)) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipGetLastError());
     c->G = in_b ? c->d_T1 : c->d_A;
     c->W1 = in_b ? c->d_A : c->d_T1;
     c->W2 = c->d_T2;
+    return NEGF_OK;
 }
 
 // Sigma blocks of a block provider for energies E[0..nb) -> c->d_blk
@@ -733,7 +740,7 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
-        run_inverse(c, nb, c->d_info + m0);
+        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
         ProfScope ps(c, "accumulate");
         launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out, c->W2);
     }
@@ -763,7 +770,7 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
-        run_inverse(c, nb, c->d_info + m0);
+        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
         if (compact_available(c, p)) {
             // G Gamma G^H = (G[:, I] Gamma_II) G[:, I]^H : Gc and X live in the free buffer W2
             GammaSmall g;
@@ -822,7 +829,7 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
     for (int m0 = 0; m0 < m; m0 += half) {
         const int nb = std::min(half, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
-        run_inverse(c, nb, c->d_info + m0);
+        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
         if (spin_mode == NEGF_SPIN_RESTRICTED && compact_available(c, p)) {
             // T = Re sum_ij Y_ij conj(G_ij), Y = Gamma_L G Gamma_R: only G[I_L, I_R] enters
             GammaSmall gL, gR;
@@ -973,7 +980,7 @@ int negf_gr_batch(negf_ctx* c, int handle, int m, const double* E, double* G_out
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
-        run_inverse(c, nb, c->d_info + m0);
+        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
         if ((rc = download(c, reinterpret_cast<cplx*>(G_out) + n2 * m0, c->G, n2 * nb))) return rc;
     }
     c->last_m = m;
@@ -1019,7 +1026,7 @@ int negf_dos(negf_ctx* c, int handle, int m, const double* E, double* dos_total,
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
-        run_inverse(c, nb, c->d_info + m0);
+        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
         { ProfScope ps(c, "trace"); launch_dos(c->stream, c->n, nb, c->G, c->d_scal + m0, dos_site ? c->d_site : nullptr); }
         if (dos_site && (rc = download(c, dos_site + (size_t)m0 * c->n, c->d_site, (size_t)nb * c->n))) return rc;
     }

@@ -174,8 +174,9 @@ void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S
                      const int* d_blk_off, const int* d_inds_off, const int* d_inds,
                      cplx* A);
 
-// in-place inverse of nb matrices; info[b] = 0 or 1-based column of a zero pivot
-void launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
+// in-place inverse of nb matrices; info[b] = 0 or 1-based column of a zero pivot.  false: n exceeds what the
+// kernel's LDS staging holds (nothing launched)
+bool launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
 // out-of-place ping-pong between A and B (both [nb][stride]); returns true when the
 // inverses end up in B, false when in A
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info);

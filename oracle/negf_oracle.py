@@ -355,11 +355,14 @@ def bethe_contact_sigma(E, N, atom_inds, atom_nInds, H, Slist, Vlist, eta,
     return sig
 
 
-def bethe_cluster_sigma_total(E, H, Slist, Vlist, eta, **kw):
+def bethe_cluster_sigma_total(E, H, Slist, Vlist, eta, sigK=None, **kw):
     """surfGBethe.py:1129-1136 -- 117 x 117 block-diagonal self-energy of the
     13-site cluster used for the contact Fermi level: block k (k<12) holds
-    Sigma_tot - sigma_{(k+6)%12}; the centre block (last) stays zero."""
-    sigK, _, _ = bethe_sigmaK(E, H, Slist, Vlist, eta, **kw)
+    Sigma_tot - sigma_{(k+6)%12}; the centre block (last) stays zero.
+    ``sigK``: given bulk self-energies (pinning against the reference's numpy twin,
+    surfG3D.py:998-1031, which is handed the same set)."""
+    if sigK is None:
+        sigK, _, _ = bethe_sigmaK(E, H, Slist, Vlist, eta, **kw)
     NN = len(Slist)
     tot = np.sum(sigK, axis=0)
     out = np.zeros(((NN + 1) * DIM, (NN + 1) * DIM), dtype=complex)

@@ -299,8 +299,10 @@ def main():
     Fo, So, st, G1, G2 = ons["create_realistic_transport_system"](24)
     out["rts24_F"] = Fo; out["rts24_S"] = So; out["rts24_sigma"] = st
     out["rts24_G1"] = G1; out["rts24_G2"] = G2
-    # inline numpy check of tests/jax_optimization_suite.py:165-194, restated here
-    # verbatim in form (np.linalg.inv, trace of the triple product)
+    # BUILDER RESTATEMENT (not reference output): the check of tests/jax_optimization_suite.py:165-194
+    # inlines its numpy twin inside a test function that also calls the jax kernels, so it cannot be
+    # extracted on its own; the same two expressions are written out here (np.linalg.inv, trace of the
+    # triple product).  The inputs above (rts24_F ... rts24_G2) ARE reference output.
     es = np.linspace(-2, 2, 7)
     Ts, Ds = [], []
     for E in es:
@@ -313,6 +315,54 @@ def main():
 
     np.savez_compressed(os.path.join(OUT, "ref_numpy_restatements.npz"), **out)
     print("ref_numpy_restatements.npz:", len(out), "arrays")
+
+    # ------------------------------------------- Bethe lattice: the reference's numpy twin (surfG3D.py)
+    # gauNEGF/surfG3D.py is a numpy-only copy of surfGBethe.py's parser, neighbour generator and
+    # Slater-Koster construction (:137-385), of the SURFACE fixed point (surfGAt.sigma, :907-979) and of
+    # the 13-site cluster assembly (surfGAt.sigmaTot, :998-1031).  Its bulk loop (surfGAt.sigmaK) is a
+    # different, Jacobi-type iteration than surfGBethe.py:958-1030 and is NOT used: the bulk self-energies
+    # the surface loop starts from are INJECTED (a fixed, seeded set), so that exactly the code of the
+    # surface loop / the cluster assembly is what produces the vectors.
+    out = {}
+    from numpy import linalg as LA
+    g3 = {"np": np, "LA": LA, "ETA": cfg.ETA, "TEMPERATURE": cfg.TEMPERATURE, "ENERGY_MIN": cfg.ENERGY_MIN}
+    extract("gauNEGF/surfG3D.py", ["kB", "dim", "har_to_eV", "Eminf", "surfG3", "surfGAt"], g3)
+    for name in ("Au", "Au2"):
+        dev = object.__new__(g3["surfG3"])                 # methods only: the constructor needs Gaussian
+        dev.readBetheParams(os.path.join(REF, name))
+        out[f"{name}_ne"] = np.array(dev.ne)
+        out[f"{name}_H0"] = dev.H0
+        for dname, d in (("E", dev.Edict), ("V", dev.Vdict), ("S", dev.Sdict)):
+            keys = sorted(d)
+            out[f"{name}_{dname}_keys"] = np.array(keys)
+            out[f"{name}_{dname}_vals"] = np.array([d[k] for k in keys])
+        geoms = [(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.2, 0.0])),
+                 (np.array([1.0, 1.0, 1.0]) / np.sqrt(3.0), np.array([0.3, -1.0, 0.4]))]
+        for gi, (normal, first) in enumerate(geoms):
+            dirs = dev.genNeighbors(normal, first.copy())
+            out[f"{name}_g{gi}_normal"] = normal; out[f"{name}_g{gi}_first"] = first
+            out[f"{name}_g{gi}_dirs"] = np.array(dirs)
+            out[f"{name}_g{gi}_Slist"] = np.array([dev.constructMat(dev.Sdict, d) for d in dirs])
+            out[f"{name}_g{gi}_Vlist"] = np.array([dev.constructMat(dev.Vdict, d) for d in dirs])
+        Sl = list(out[f"{name}_g0_Slist"]); Vl = list(out[f"{name}_g0_Vlist"])
+        eta = 1e-6
+        at = g3["surfGAt"](dev.H0.copy(), [m.copy() for m in Sl], [m.copy() for m in Vl], eta)
+        out[f"{name}_cluster_F"] = at.F; out[f"{name}_cluster_S"] = at.S
+        rng = np.random.default_rng(11)
+        energies = np.array([-5.0, 0.7, 2.5])
+        out[f"{name}_energies"] = energies
+        out[f"{name}_eta"] = np.array(eta)
+        for ie, E in enumerate(energies):
+            # a fixed, physically shaped bulk set: -i I plus a seeded symmetric perturbation
+            pert = rng.standard_normal((12, 9, 9)) * 0.05
+            sigK = np.array([-1j * np.eye(9) + (p_ + p_.T) * (0.3 - 0.2j) for p_ in pert])
+            at.sigmaK = (lambda sk: (lambda E_, conv=1e-5, mix=0.5: sk.copy()))(sigK)
+            out[f"{name}_e{ie}_sigK"] = sigK
+            surf = quiet(at.sigma, float(E), None, 1e-5, 0.5)
+            out[f"{name}_e{ie}_surface"] = np.array(surf)
+            out[f"{name}_e{ie}_cluster"] = quiet(at.sigmaTot, float(E), 1e-5)
+    np.savez_compressed(os.path.join(OUT, "ref_bethe.npz"), **out)
+    print("ref_bethe.npz:", len(out), "arrays")
     print("numpy", np.__version__, "scipy", scipy.__version__)
 
 

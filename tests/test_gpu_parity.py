@@ -504,6 +504,20 @@ def test_bethe_raw_fixed_trip_count(engine, name):
     assert rel_fro(at.sigmaTot(-5.0), cl) < 1e-10
 
 
+@pytest.mark.parametrize("name", ["Au", "Au2"])
+def test_bethe_surface_loop_given_device_bulk(engine, name):
+    """The oracle's surface loop is pinned to the reference's numpy twin (surfG3D.py:907-979,
+    test_oracle_golden.py); started from the DEVICE's own bulk self-energies it must reproduce the device's
+    surface self-energies, and the pinned cluster assembly the device's cluster matrix."""
+    at, H0, Sl, Vl = _bethe_atom(name)
+    at.force_iters = 25
+    for E in (-5.0, 0.7, -2.0 + 0.3j):
+        sigK = at.sigmaK(E)
+        ref9, _, _, _ = oracle.bethe_sigma_surface(E, H0, Sl, Vl, 1e-6, force_iters=25, sigK=sigK)
+        assert rel_fro(at.sigma(E), ref9) < 1e-10, (name, E)
+        assert rel_fro(at.sigmaTot(E), oracle.bethe_cluster_sigma_total(E, H0, Sl, Vl, 1e-6, sigK=sigK)) < 1e-13
+
+
 def test_bethe_raw_free_running(engine):
     at, H0, Sl, Vl = _bethe_atom()
     E = np.array([-6.0, -5.0, -3.0, 1.0])

@@ -193,3 +193,36 @@ def test_bethe_invariants():
     for k in (0, 1, 2, 6, 7, 8):
         B = z * Sl[k] - Vl[k]
         assert rel_fro(s9[k], B @ gs @ B.conj().T) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["Au", "Au2"])
+def test_bethe_setup_and_loops_vs_reference_numpy_twin(golden_bethe, name):
+    """gauNEGF/surfG3D.py is the reference's numpy-only twin of surfGBethe.py (parser, neighbour generator,
+    Slater-Koster blocks :137-385, surface fixed point :907-979, cluster assembly :998-1031).  Its output
+    (tests/golden/ref_bethe.npz, produced by executing that code) pins the product's host-side setup and
+    the oracle's surface loop / cluster assembly; the bulk self-energies are the injected set of the file."""
+    import os
+    from gaunegf_amd.surfGBethe import read_bethe_params, gen_neighbors, construct_sk_matrix, surfGBAt
+    g = golden_bethe
+    here = os.path.join(os.path.dirname(__file__), "golden", name)
+    ne, Ed, Vd, Sd, H0 = read_bethe_params(here)
+    assert ne == float(g[f"{name}_ne"]) and np.array_equal(H0, g[f"{name}_H0"])
+    for tag, d in (("E", Ed), ("V", Vd), ("S", Sd)):
+        assert sorted(d) == list(g[f"{name}_{tag}_keys"])
+        assert np.array_equal(np.array([d[k] for k in sorted(d)]), g[f"{name}_{tag}_vals"])
+    for gi in (0, 1):
+        dirs = gen_neighbors(g[f"{name}_g{gi}_normal"], g[f"{name}_g{gi}_first"].copy())
+        assert np.max(np.abs(np.array(dirs) - g[f"{name}_g{gi}_dirs"])) < 1e-15
+        for tag, d in (("Slist", Sd), ("Vlist", Vd)):
+            got = np.array([construct_sk_matrix(d, v) for v in g[f"{name}_g{gi}_dirs"]])
+            ref = g[f"{name}_g{gi}_{tag}"]
+            assert np.max(np.abs(got - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref))), (gi, tag)
+    Sl = list(g[f"{name}_g0_Slist"]); Vl = list(g[f"{name}_g0_Vlist"]); eta = float(g[f"{name}_eta"])
+    at = surfGBAt(H0, Sl, Vl, eta)
+    assert np.array_equal(at.F, g[f"{name}_cluster_F"]) and np.array_equal(at.S, g[f"{name}_cluster_S"])
+    for ie, E in enumerate(g[f"{name}_energies"]):
+        sigK = g[f"{name}_e{ie}_sigK"]
+        surf, count, diff, _ = oracle.bethe_sigma_surface(float(E), H0, Sl, Vl, eta, sigK=sigK)
+        assert rel_fro(surf, g[f"{name}_e{ie}_surface"]) < 1e-12, (name, E, count)
+        cl = oracle.bethe_cluster_sigma_total(float(E), H0, Sl, Vl, eta, sigK=sigK)
+        assert rel_fro(cl, g[f"{name}_e{ie}_cluster"]) < 1e-14
