@@ -100,9 +100,14 @@ void free_mbuffers(negf_ctx* c)
     c->m_cap = 0; c->contacts_cap = 0;
 }
 
+// Energies in flight for a grid of m points.  The workspace is sized for TWICE the grid (the transmission
+// entry point carves two work areas per energy out of it) so that the calls of one workflow -- GrInt, then
+// calculate_transmission, then GrLessInt on the same grid -- find it in place: it only ever grows, and only
+// when a larger grid arrives.
 int auto_batch(negf_ctx* c, int m)
 {
     if (c->batch_user > 0) return std::min(c->batch_user, std::max(m, 1));
+    m = 2 * std::max(m, 1);
     // three n x n complex128 work matrices per in-flight energy.  The working set may take a
     // quarter of the free HBM (288 GB per MI355X), at most 64 GB: large matrices need hundreds of
     // energies in flight so that the one-workgroup-per-matrix panel kernels cover the 256 CUs
@@ -821,7 +826,7 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
     if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
     // two extra n x n work areas per energy for Gamma_L / Gamma_R: reuse T1/T2 for
     // the Gammas and carve the product temporaries out of a second workspace half
-    if ((rc = ensure_workspace(c, 2 * std::max(m, 1), p->blk_stride, 2))) return rc;
+    if ((rc = ensure_workspace(c, m, p->blk_stride, 2))) return rc;
     const cplx* E = reinterpret_cast<const cplx*>(E_dev);
     // process with half the allocated batch so that [0,half) holds this sweep's
     // matrices and [half, 2*half) is free scratch in each of A/T1/T2

@@ -80,6 +80,44 @@ def allreduce_sum_tensor(t):
     return t
 
 
+def barrier():
+    if is_active():
+        _dist().barrier(group=_state["group"])
+
+
+def sharded_device_sum(engine, run_dev, E, w):
+    """Device-resident integral over this rank's cyclic shard of the grid (E, w: complex128 numpy
+    arrays, the same on every rank).  ``run_dev(m, E_ptr, w_ptr, out_ptr)`` launches the engine's
+    ``*_dev`` entry point on the rank's shard; the partial n x n sum stays in HBM, is all-reduced in place
+    -- ONE collective of 2 n^2 doubles (RCCL over xGMI with the nccl backend) -- and is downloaded once.
+    With a CPU backend (gloo: tests, rehearsals on one GPU) the partial sum is staged through the host
+    for the collective only."""
+    import torch
+    dist = _dist()
+    rank, world = rank_world()
+    idx = shard_indices(E.size, rank, world)
+    dev = torch.device("cuda", engine.device)
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        return torch.view_as_complex(torch.from_numpy(a.view(np.float64).reshape(-1, 2).copy())).to(dev)
+    out = torch.zeros((engine.n, engine.n), dtype=torch.complex128, device=dev)
+    if idx.size:
+        E_t, w_t = to_dev(E[idx]), to_dev(w[idx])
+        run_dev(int(idx.size), E_t.data_ptr(), w_t.data_ptr(), out.data_ptr())
+    # (an empty shard -- fewer points than ranks -- still takes part in the collective, with zeros)
+    engine.sync()                                   # the engine's stream -> visible to the collective's stream
+    if idx.size:
+        engine.warn_if_singular_dev(int(idx.size), "sharded integral")
+    flat = torch.view_as_real(out)
+    if dist.get_backend(_state["group"]) == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_state["group"])
+        return out.cpu().numpy()
+    host = flat.cpu()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_state["group"])
+    return torch.view_as_complex(host).numpy().copy()
+
+
 def sharded_sum(partial_fn, m):
     """``partial_fn(idx)`` returns the partial sum over energy indices ``idx``;
     returns the full sum on every rank."""

@@ -297,6 +297,11 @@ class Engine:
         check(self._lib.negf_last_info(self._ctx, int(m), _ptr(info)), "negf_last_info")
         return info[:m]
 
+    def warn_if_singular_dev(self, m, where):
+        """The *_dev entry points return no per-energy info: fetch it and warn like the host variants."""
+        info = self.last_info_dev(m)
+        self._numerical(_lib.NEGF_ESINGULAR if np.any(info) else 0, info, where)
+
     def last_iters_dev(self, handle, m, n_contacts):
         """(sweeps, converged) [m, n_contacts] of the fixed points run by the last call."""
         it = np.zeros((max(m, 1), max(n_contacts, 1)), dtype=np.int32)

@@ -98,6 +98,10 @@ def GrInt(F, S, g, Elist, weights):
     engine.set_system(F, S)
     E = np.ascontiguousarray(E.ravel(), dtype=np.complex128)
     w = np.ascontiguousarray(w.ravel(), dtype=np.complex128)
+    if _dist.is_active() and hasattr(g, "_negf_lower"):
+        # N > 1: the partial sum never leaves HBM before the (single) all-reduce
+        h = g._negf_lower(engine)
+        return _dist.sharded_device_sum(engine, lambda m, Ep, wp, op: engine.gr_int_dev(h, m, Ep, wp, op), E, w)
     return _dist.sharded_sum(lambda idx: _partial_gr(engine, g, E[idx], w[idx]), E.size)
 
 
@@ -112,6 +116,10 @@ def GrLessInt(F, S, g, Elist, weights, ind=None):
     engine.set_system(F, S)
     E = np.ascontiguousarray(E.ravel(), dtype=np.complex128)
     w = np.ascontiguousarray(w.ravel(), dtype=np.complex128)
+    if _dist.is_active() and hasattr(g, "_negf_lower"):
+        h = g._negf_lower(engine)
+        return _dist.sharded_device_sum(
+            engine, lambda m, Ep, wp, op: engine.gless_int_dev(h, ind, m, Ep, wp, op), E, w)
     return _dist.sharded_sum(lambda idx: _partial_gless(engine, g, E[idx], w[idx], ind), E.size)
 
 

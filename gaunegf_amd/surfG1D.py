@@ -121,11 +121,9 @@ class surfG:
         key = (id(engine), getattr(engine, "generation", 0), self._version, float(conv), float(relFactor),
                bool(identity_tau), float(self.eta), int(self.force_iters))
         if key in self._lowered:
-            return self._lowered[key]
+            return self._lowered[key][1]
         if len(self._lowered) > 8:
-            for h in self._lowered.values():
-                engine.sigma_free(h)
-            self._lowered.clear()
+            self._release()
         ids = self._contact_ids()
         nc = [len(self.indsList[i]) for i in ids]
         taus, staus = [], []
@@ -143,8 +141,20 @@ class surfG:
                                  [self.bList[i] for i in ids], [self.bSList[i] for i in ids],
                                  taus, staus, self.eta, conv, relFactor,
                                  max_iter=SURFACE_GREEN_MAX_ITER, force_iters=self.force_iters)
-        self._lowered[key] = h
+        self._lowered[key] = (engine, h)
         return h
+
+    def _release(self):
+        # handles are never reused by the library: freeing a stale one is a no-op there
+        for eng, h in self._lowered.values():
+            eng.sigma_free(h)
+        self._lowered.clear()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
     # ---- reference protocol ------------------------------------------------
     def g(self, E, i, conv=SURFACE_GREEN_CONVERGENCE, relFactor=SURFACE_RELAXATION_FACTOR):

@@ -369,17 +369,27 @@ class surfGB:
         key = (id(engine), getattr(engine, "generation", 0), self._version, float(conv),
                tuple(g._version for g in self.gList), int(self.force_iters))
         if key in self._lowered:
-            return self._lowered[key]
-        for h in self._lowered.values():
-            engine.sigma_free(h)
-        self._lowered.clear()
+            return self._lowered[key][1]
+        self._release()
         xi = self.Xi if self.Sdict['sss'] == 0 else None
         h = engine.sigma_bethe(self.indsLists, self.nIndLists, [g.H for g in self.gList],
                                [np.stack(g.Slist) for g in self.gList],
                                [np.stack(g.Vlist) for g in self.gList], xi, self.eta, conv, BETHE_MIX,
                                BETHE_MAX_ITER, self.force_iters)
-        self._lowered[key] = h
+        self._lowered[key] = (engine, h)
         return h
+
+    def _release(self):
+        # handles are never reused by the library: freeing a stale one is a no-op there
+        for eng, h in self._lowered.values():
+            eng.sigma_free(h)
+        self._lowered.clear()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
     def _expand_spin(self, sig):
         if self.spin in ('u', 'ro'):

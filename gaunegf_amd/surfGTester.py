@@ -55,7 +55,20 @@ class surfGTest:
     def _negf_lower(self, engine):
         key = (id(engine), getattr(engine, "generation", 0))
         if key not in self._lowered:
-            self._lowered.clear()
+            self._release()
             mats = [self.sig[i] for i in range(len(self.indsList))]
-            self._lowered[key] = engine.sigma_const(mats)
-        return self._lowered[key]
+            self._lowered[key] = (engine, engine.sigma_const(mats))
+        return self._lowered[key][1]
+
+    def _release(self):
+        # handles are never reused by the library: freeing one that a change of the matrix dimension
+        # already dropped is a no-op there
+        for eng, h in self._lowered.values():
+            eng.sigma_free(h)
+        self._lowered.clear()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass

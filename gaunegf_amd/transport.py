@@ -239,6 +239,17 @@ def _dos_result(total, per_site, spin):
 # --------------------------------------------------------------------------- #
 # front-ends with the reference's checkpoint semantics
 # --------------------------------------------------------------------------- #
+def _write_checkpoint(path, **arrays):
+    """One writer (rank 0 when the energy grid is sharded over ranks), through a temporary file and an
+    atomic rename: a reader -- this run's resume, or another rank -- never sees a torn .npz."""
+    if _dist.rank_world()[0] != 0:
+        return
+    target = path if path.endswith(".npz") else path + ".npz"       # np.savez appends the suffix
+    tmp = target + ".tmp.npz"
+    np.savez(tmp, **arrays)
+    os.replace(tmp, target)
+
+
 def _chunks(remaining, checkpoint_file, checkpoint_interval):
     if not checkpoint_file:
         return [remaining] if len(remaining) else []
@@ -275,10 +286,10 @@ def calculate_transmission(F, S, sigma_calculator, energy_list, spin=None, check
 
     def save():
         if spin_trans is not None:
-            np.savez(checkpoint_file, transmission=transmission, spin_transmission=spin_trans,
-                     energy_list=energy_list)
+            _write_checkpoint(checkpoint_file, transmission=transmission, spin_transmission=spin_trans,
+                              energy_list=energy_list)
         else:
-            np.savez(checkpoint_file, transmission=transmission, energy_list=energy_list)
+            _write_checkpoint(checkpoint_file, transmission=transmission, energy_list=energy_list)
 
     remaining = np.where(transmission == -1)[0]
     for chunk in _chunks(remaining, checkpoint_file, checkpoint_interval):
@@ -333,11 +344,11 @@ def calculate_dos(F, S, sigma_calculator, energy_list, spin=None, checkpoint_fil
 
     def save():
         if dos_spin is not None:
-            np.savez(checkpoint_file, dos_total=dos_total, dos_per_site=dos_per_site, dos_spin=dos_spin,
-                     energy_list=energy_list)
+            _write_checkpoint(checkpoint_file, dos_total=dos_total, dos_per_site=dos_per_site, dos_spin=dos_spin,
+                              energy_list=energy_list)
         else:
-            np.savez(checkpoint_file, dos_total=dos_total, dos_per_site=dos_per_site,
-                     energy_list=energy_list)
+            _write_checkpoint(checkpoint_file, dos_total=dos_total, dos_per_site=dos_per_site,
+                              energy_list=energy_list)
 
     remaining = np.where(dos_total == -1)[0]
     for chunk in _chunks(remaining, checkpoint_file, checkpoint_interval):

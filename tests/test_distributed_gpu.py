@@ -1,0 +1,96 @@
+"""
+The N > 1 path driven through the HIP engine: two FRESH child processes (spawn; gloo backend, both on
+device 0 -- RCCL refuses two ranks on one device, and the one-GPU box has one) run GrInt / GrLessInt /
+calculate_transmission with gaunegf_amd.distributed enabled: cyclic shard of the grid, the engine's *_dev entry
+points on each rank's shard, ONE sum all-reduce.  The result must equal the single-process integral.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import chain_lead, random_system
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _systems():
+    from gaunegf_amd.surfGTester import surfGTest
+    from gaunegf_amd.surfG1D import surfG
+    N, nc = 48, 6
+    F, S = random_system(N, 12)
+    inds = [list(range(nc)), list(range(N - nc, N))]
+    g_const = surfGTest(F, S, inds, -0.1j)
+    aL = chain_lead(nc, 41); aR = chain_lead(nc, 42)
+    g_chain = surfG(F, S, inds, taus=[aL[2].copy(), aR[2].copy()], staus=[aL[3].copy(), aR[3].copy()],
+                    alphas=[aL[0], aR[0]], aOverlaps=[aL[1], aR[1]], betas=[aL[2], aR[2]],
+                    bOverlaps=[aL[3], aR[3]], eta=1e-3)
+    g_chain.force_iters = 30
+    M = 37                                         # not divisible by the world size: ragged shards
+    E = np.linspace(-1.5, 1.5, M) + 0.0j
+    w = (np.cos(np.arange(M)) + 1.5) * (3.0 / M) + 0.0j
+    return F, S, g_const, g_chain, E, w
+
+
+def _run_all(F, S, g_const, g_chain, E, w):
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+    out = {"gr_const": GrInt(F, S, g_const, E, w), "gless_const": GrLessInt(F, S, g_const, E, w, -1),
+           "gr_chain": GrInt(F, S, g_chain, E, w), "gless_chain": GrLessInt(F, S, g_chain, E, w, 0),
+           "T": calculate_transmission(F, S, SigmaCalculator(g_const.sig[0], g_const.sig[1]), np.real(E)),
+           "gr_one": GrInt(F, S, g_const, E[:1], w[:1])}      # one point: the second rank's shard is empty
+    return out
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from gaunegf_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"                 # both ranks on the one visible GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D.enable()
+        res = _run_all(*_systems())
+        maps = open("/proc/self/maps").read()
+        if rank == 0:
+            q.put((res, "libnegf_hip.so" in maps))
+    finally:
+        D.disable()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_engine_match_one_process(engine):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    res = None
+    for _ in range(60):                                 # fail as soon as a rank has died, not after a long wait
+        try:
+            res, loaded = q.get(timeout=5)
+            break
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    if res is None:
+        for p in procs:
+            p.kill()
+        pytest.fail("a rank died (its traceback is on stderr)")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert loaded
+    ref = _run_all(*_systems())
+    for k in ("gr_const", "gless_const", "gr_chain", "gless_chain", "gr_one"):
+        assert np.linalg.norm(res[k] - ref[k]) <= 1e-13 * np.linalg.norm(ref[k]), k
+    assert np.array_equal(res["T"], ref["T"])          # zero-filled all-reduce of per-energy scalars is exact

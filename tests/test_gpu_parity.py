@@ -121,6 +121,26 @@ def test_api_assertions_and_edges(engine):
         GrLessInt(F, S, g_dev, E, w, 5)
 
 
+def test_workspace_is_stable_across_entry_points(engine):
+    """One workflow on one grid -- GrInt, calculate_transmission, GrLessInt, DOS, GrInt -- must not re-allocate
+    the batch workspace between calls (the transmission needs two work areas per energy; the workspace is
+    sized for that from the first call on)."""
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission, calculate_dos
+    N = 72
+    F, S, g_dev, g_ref = _const_provider(N, 19)
+    E = np.linspace(-1.0, 1.0, 37); w = np.full(37, 2.0 / 37)
+    sc = SigmaCalculator(g_dev.sig[0], g_dev.sig[1])
+    GrInt(F, S, g_dev, E, w)
+    b0 = engine.get_batch()
+    assert b0 >= 2 * len(E)
+    for call in (lambda: calculate_transmission(F, S, sc, E), lambda: GrLessInt(F, S, g_dev, E, w, -1),
+                 lambda: calculate_dos(F, S, sc, E), lambda: GrInt(F, S, g_dev, E[:11], w[:11]),
+                 lambda: calculate_transmission(F, S, sc, E[:5])):
+        call()
+        assert engine.get_batch() == b0
+
+
 @pytest.mark.parametrize("N", [2100, 4200])
 def test_largest_window_configurations(engine, N):
     """n > 2048 runs the windowed path with 8 rows per lane and sub-panels of 4 columns, n > 4096 with
