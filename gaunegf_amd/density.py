@@ -276,6 +276,43 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
 
 
 # ------------------------------------------------------------- DOS at one E
+# --------------------------------------------------------------------------- #
+# closed-form density for energy-independent self-energies (density.py:276-382)
+# --------------------------------------------------------------------------- #
+def density(V, Vc, D, Gam, Emin, mu):
+    """int_{Emin}^{mu} G Gamma G^H dE / 2 pi in closed form (Eq. 27 of PRB 65, 165401) for a constant
+    self-energy: with  X (F + Sigma) X = V diag(D) V^-1  and  Vc = (V^H)^-1,
+        P = V [ L o (Vc^H Gam Vc) ] V^H,   L_ij = (l_i - conj(l_j)) / (2 pi (D_i - conj(D_j))),
+        l_i = log(1 - mu / D_i) - log(1 - Emin / D_i)            (complex logarithms),
+    in the orthogonalised basis (density.py:276-329).  O(N^3) once, no energy grid: host numpy."""
+    D = np.asarray(D)
+    l = np.emath.log(1 - (mu / D)) - np.emath.log(1 - (Emin / D))
+    L = (l[:, None] - l.conj()[None, :]) / (2 * np.pi * (D[:, None] - D.conj()[None, :]))
+    return V @ (L * (Vc.conj().T @ Gam @ Vc)) @ V.conj().T
+
+
+def bisectFermi(V, Vc, D, Gam, Nexp, conv=None, Eminf=None):
+    """Bisection on the closed-form electron count between the lowest and highest level
+    (density.py:331-382); prints the reference's messages."""
+    from .config import FERMI_CALCULATION_TOL, ENERGY_MIN
+    conv = FERMI_CALCULATION_TOL if conv is None else conv
+    Eminf = ENERGY_MIN if Eminf is None else Eminf
+    Emin, Emax = min(np.real(D)), max(np.real(D))
+    dN, Niter, fermi_ = Nexp, 0, None
+    while abs(dN) > conv and Niter < 1000:
+        fermi_ = (Emin + Emax) / 2
+        dN = np.trace(density(V, Vc, D, Gam, Eminf, fermi_)).real - Nexp
+        if dN > 0:
+            Emax = fermi_
+        else:
+            Emin = fermi_
+        Niter += 1
+    if Niter >= 1000:
+        print('Warning: Bisection search timed out after 1000 iterations!')
+    print(f'Bisection fermi search converged to {dN:.2E} in {Niter} iterations.')
+    return fermi_
+
+
 def _compute_dos_at_energy(E, F, S, sigma_total):
     """-Im Tr G / pi at one energy with an explicit Sigma (density.py:49-54)."""
     from .engine import get_engine

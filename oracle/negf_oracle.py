@@ -16,7 +16,8 @@ __all__ = [
     "bethe_atom_sigma", "bethe_contact_sigma", "bethe_cluster_sigma_total",
     "fermi", "ant_points", "real_axis_grid", "bias_window_grid", "contour_grid",
     "broadening_grid", "adaptive_ant", "current_grid", "current_from_transmission",
-    "ConstSigma", "Chain1DSigma", "kB", "eoverh", "N_KT", "DIM",
+    "ConstSigma", "Chain1DSigma", "kB", "eoverh", "N_KT", "DIM", "density_analytic",
+    "density_analytic_from_system",
 ]
 
 kB = 8.617e-5          # eV/K      (density.py:61, transport.py:36)
@@ -370,6 +371,36 @@ def bethe_cluster_sigma_total(E, H, Slist, Vlist, eta, sigK=None, **kw):
         pk = (k + 6) % 12
         out[k * DIM:(k + 1) * DIM, k * DIM:(k + 1) * DIM] = tot - sigK[pk]
     return out
+
+
+# --------------------------------------------------------------------------- #
+# analytic density for constant self-energies (density.py:276-329): an independent check of the
+# contour orientation and prefactors of the grid code
+# --------------------------------------------------------------------------- #
+def density_analytic(V, Vc, D, Gam, Emin, mu):
+    """density.py:276-329, operation for operation (np.emath.log, broadcast by stacking rows)."""
+    Nd = len(V)
+    DD = np.array([D for i in range(Nd)]).T
+    logmat = np.array([np.emath.log(1 - (mu / D)) for i in range(Nd)]).T
+    logmat2 = np.array([np.emath.log(1 - (Emin / D)) for i in range(Nd)]).T
+    invmat = 1 / (2 * np.pi * (DD - DD.conj().T))
+    pref2 = logmat - logmat.conj().T
+    pref3 = logmat2 - logmat2.conj().T
+    prefactor = np.multiply(invmat, (pref2 - pref3))
+    Gammam = Vc.conj().T @ Gam @ Vc
+    prefactor = np.multiply(prefactor, Gammam)
+    return V @ prefactor @ V.conj().T
+
+
+def density_analytic_from_system(F, S, sig1, sig2, Emin, mu):
+    """scf.py:553-575: P = X density(V, Vc, D, X Gamma X, Emin, mu) X for constant contacts (eV)."""
+    from scipy.linalg import fractional_matrix_power
+    X = np.array(fractional_matrix_power(S, -0.5))
+    Fbar = X @ (F + sig1 + sig2) @ X
+    Gam = X @ (1j * (sig1 - sig1.conj().T) + 1j * (sig2 - sig2.conj().T)) @ X
+    D, V = np.linalg.eig(Fbar)
+    Vc = np.linalg.inv(V.conj().T)
+    return X @ density_analytic(V, Vc, D, Gam, Emin, mu) @ X
 
 
 # --------------------------------------------------------------------------- #

@@ -25,6 +25,11 @@ def golden_num():
 
 
 @pytest.fixture(scope="session")
+def golden_analytic():
+    return np.load(os.path.join(GOLDEN, "ref_analytic_density.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def golden_bethe():
     return np.load(os.path.join(GOLDEN, "ref_bethe.npz"), allow_pickle=False)
 

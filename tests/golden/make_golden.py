@@ -363,6 +363,31 @@ def main():
             out[f"{name}_e{ie}_cluster"] = quiet(at.sigmaTot, float(E), 1e-5)
     np.savez_compressed(os.path.join(OUT, "ref_bethe.npz"), **out)
     print("ref_bethe.npz:", len(out), "arrays")
+
+    # ------------------------- analytic density for constant self-energies (density.py:276-382, numpy only)
+    out = {}
+    ans = {"np": np, "FERMI_CALCULATION_TOL": cfg.FERMI_CALCULATION_TOL, "ENERGY_MIN": cfg.ENERGY_MIN}
+    extract("gauNEGF/density.py", ["density", "bisectFermi"], ans)
+    from scipy.linalg import fractional_matrix_power
+    rng = np.random.default_rng(21)
+    Na = 10
+    A_ = rng.standard_normal((Na, Na)); Fa = (A_ + A_.T) * (1.0 / np.sqrt(2 * Na)) * 2
+    B_ = rng.standard_normal((Na, Na)); Sa = np.eye(Na) + 0.1 * (B_ + B_.T) / np.sqrt(2 * Na)
+    s1 = mns["formSigma"]([0, 1], -0.1j, Na, Sa); s2 = mns["formSigma"]([8, 9], -0.15j, Na, Sa)
+    X = np.array(fractional_matrix_power(Sa, -0.5))
+    Fbar = X @ (Fa + s1 + s2) @ X
+    Gam = X @ (1j * (s1 - s1.conj().T) + 1j * (s2 - s2.conj().T)) @ X
+    Dv, Vv = np.linalg.eig(Fbar)
+    Vc = np.linalg.inv(Vv.conj().T)
+    out["an_F"] = Fa; out["an_S"] = Sa; out["an_sig1"] = s1; out["an_sig2"] = s2
+    out["an_D"] = Dv; out["an_V"] = Vv; out["an_Vc"] = Vc; out["an_Gam"] = Gam; out["an_X"] = X
+    for i, (Emin_, mu_) in enumerate([(-1e6, 0.2), (-40.0, -0.5), (-6.0, 1.0)]):
+        out[f"an{i}_limits"] = np.array([Emin_, mu_])
+        out[f"an{i}_Pbar"] = ans["density"](Vv, Vc, Dv, Gam, Emin_, mu_)
+    out["an_bisect_Nexp"] = np.array(4.3)
+    out["an_bisect_fermi"] = np.array(quiet(ans["bisectFermi"], Vv, Vc, Dv, Gam, 4.3, 1e-6, -1e6))
+    np.savez_compressed(os.path.join(OUT, "ref_analytic_density.npz"), **out)
+    print("ref_analytic_density.npz:", len(out), "arrays")
     print("numpy", np.__version__, "scipy", scipy.__version__)
 
 

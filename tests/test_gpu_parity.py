@@ -477,6 +477,53 @@ def test_chain1d_integrals_fixed_trip(engine):
         assert abs(T[k] - ref) < TOL * max(1.0, abs(ref))
 
 
+def test_surfG_from_fock_patterns_and_setF(engine):
+    """Construction from F / S alone (surfG1D.py:131-147) and setF (:297-329) end to end: the device
+    self-energy equals the oracle's for the blocks the constructor extracted, before and after a new F."""
+    from gaunegf_amd.surfG1D import surfG
+    N = 26
+    F, S = random_system(N, 8)
+    inds = [[0, 1, 2, 3], [22, 23, 24, 25]]
+    conn = [[4, 5, 6, 7], [18, 19, 20, 21]]
+    for taus in (None, conn):
+        g = surfG(F, S, inds, taus=taus, eta=1e-3)
+        g.force_iters = 20
+
+        def ref_of(g):
+            r = oracle.Chain1DSigma(g.F, g.S, inds, g.tauList, g.stauList, g.aList, g.aSList, g.bList, g.bSList,
+                                    eta=1e-3)
+            r.force_iters = 20
+            return r
+        for E in (0.2, -0.7 + 0.1j):
+            assert rel_fro(g.sigmaTot(E), ref_of(g).sigmaTot(E)) < 1e-10, (taus, E)
+        rng = np.random.default_rng(1)
+        D = rng.standard_normal((N, N)); F2 = F + 0.05 * (D + D.T)
+        g.setF(F2, 0.0, 0.0)
+        for E in (0.2, -0.7 + 0.1j):
+            assert rel_fro(g.sigmaTot(E), ref_of(g).sigmaTot(E)) < 1e-10, ("setF", taus, E)
+            assert rel_fro(g.sigma(E, -1), ref_of(g).sigma(E, 1)) < 1e-10
+
+
+def test_analytic_density_equals_grid_density(engine, golden_analytic):
+    """The reference's closed-form density for constant contacts (density.py:276-329, vectors produced by
+    executing it) against the GPU's real-axis + contour integrals of the same system: an end-to-end check of
+    the contour orientation and prefactors that does not pass through the restated grid code's oracle."""
+    from gaunegf_amd.density import densityRealN, densityComplexN
+    g = golden_analytic
+    F, S, s1, s2, X = g["an_F"], g["an_S"], g["an_sig1"], g["an_sig2"], g["an_X"]
+
+    class Const:                                     # duck-typed constant provider (host-callback path)
+        def sigmaTot(self, E): return s1 + s2
+        def sigma(self, E, i): return (s1, s2)[i]
+        def setF(self, *a): pass
+    Eminf, Emin, mu = -1e6, -8.0, 0.2
+    P = densityRealN(F, S, Const(), Eminf, Emin, 600, 0.0, showText=False) + \
+        densityComplexN(F, S, Const(), Emin, mu, 486, 0.0, showText=False)
+    Pan = np.real(X @ g["an0_Pbar"] @ X)
+    assert rel_fro(P, Pan) < 2e-4
+    assert abs(np.trace(P @ S) - np.trace(Pan @ S)) < 2e-4 * abs(np.trace(Pan @ S))
+
+
 def test_perfect_wire_closed_form(engine):
     """Tight-binding chain t=-1, eps=0, S=I with exact 1-D leads: T(E)=1 inside the band
     (SURVEY.md section 8c closed form), to O(eta, conv)."""
@@ -677,18 +724,34 @@ def test_fock_to_p_density_step(engine, capsys):
     assert sys_.updFermi
     sys_.FockToP()
     assert abs(np.real(np.trace(S @ sys_.P)) - 9.0) < 5e-3
-    with pytest.raises(NotImplementedError):
-        sys_.fermiMethod = 'predict'
+    # 'predict' (scfE.py:333-361): the constant-self-energy estimate moves the level towards the target
+    sys_ = NEGFE(F, S, g_dev, ne=2 * 9, spin='r', T=0.0, Eminf=Eminf)
+    sys_.setIntegralLimits(N1=64, N2=N2, tol=1e-4, Emin=Emin)
+    sys_.setVoltage(0.0, fermiMethod='predict')
+    start = sys_.fermi
+    errs = []
+    for _ in range(6):                                   # each step integrates up to the level the previous one set
         sys_.FockToP()
+        errs.append(abs(np.real(np.trace(S @ sys_.P)) - 9.0))
+    assert np.isfinite(sys_.fermi) and sys_.fermi != start
+    # the predictor keeps correcting by the electrons the last density was off by: the count closes in
+    assert errs[-1] < 0.1 and errs[-1] <= max(errs[:2]), errs
 
-    # a model SCF loop: Fock = F0 + U * diag(P) (a Hubbard-like mean field) converges under damping
+    # the SCF cycle (scf.py:663-800) on a model Fock builder F0 + U diag(P) (a Hubbard-like mean field):
+    # damping alone, and damping with a Pulay/DIIS step every (nPulay + 1)-th cycle
     F0 = F.copy()
-    sys_ = NEGFE(F0, S, g_dev, ne=18, spin='r', T=T, Eminf=Eminf,
-                 fock_builder=lambda P: F0 + 0.3 * np.diag(np.real(np.diag(P))))
-    sys_.setIntegralLimits(N1=N1, N2=N2, tol=1e-4, Emin=Emin)
-    sys_.setVoltage(0.0, fermi=mu)
-    hist = sys_.SCF(conv=1e-6, damping=0.5, maxcycles=40)
-    assert hist and hist[-1] < 1e-6
+    hist = {}
+    for pulay in (False, True):
+        sys_ = NEGFE(F0, S, g_dev, ne=18, spin='r', T=T, Eminf=Eminf,
+                     fock_builder=lambda P: F0 + 0.3 * np.diag(np.real(np.diag(P))))
+        sys_.setIntegralLimits(N1=N1, N2=N2, tol=1e-4, Emin=Emin)
+        sys_.setVoltage(0.0, fermi=mu)
+        hist[pulay] = sys_.SCF(conv=1e-6, damping=0.5, maxcycles=60, pulay=pulay)
+        assert hist[pulay][-1] < 1e-6, pulay
+        P_fix = sys_.P
+        sys_.FockToP()                                   # self-consistency: the density of the final Fock matrix
+        assert np.max(np.abs(np.diag(sys_.P) - np.diag(P_fix))) < 1e-5
+    assert len(hist[True]) <= len(hist[False])           # DIIS does not need more cycles than damping
 
 
 def test_full_size_properties_C2(engine):

@@ -226,3 +226,34 @@ def test_bethe_setup_and_loops_vs_reference_numpy_twin(golden_bethe, name):
         assert rel_fro(surf, g[f"{name}_e{ie}_surface"]) < 1e-12, (name, E, count)
         cl = oracle.bethe_cluster_sigma_total(float(E), H0, Sl, Vl, eta, sigK=sigK)
         assert rel_fro(cl, g[f"{name}_e{ie}_cluster"]) < 1e-14
+
+
+def test_analytic_density_vs_reference_and_grid_integrals(golden_analytic, capsys):
+    """density() / bisectFermi() of the reference (density.py:276-382, numpy only, executed by
+    make_golden.py) pin the oracle's and the product's closed form; and the closed form -- which knows
+    nothing of grids -- checks the contour orientation and the prefactors of the grid code: for constant
+    contacts  -Im int_{Eminf}^{Emin} G/pi + Im oint_{Emin}^{mu} G/pi  ==  int_{Eminf}^{mu} G Gamma G^H / 2 pi."""
+    from gaunegf_amd.density import density as density_prod, bisectFermi as bisect_prod
+    g = golden_analytic
+    V, Vc, D, Gam = g["an_V"], g["an_Vc"], g["an_D"], g["an_Gam"]
+    for i in range(3):
+        Emin, mu = g[f"an{i}_limits"]
+        ref = g[f"an{i}_Pbar"]
+        assert rel_fro(oracle.density_analytic(V, Vc, D, Gam, Emin, mu), ref) < 1e-14
+        assert rel_fro(density_prod(V, Vc, D, Gam, Emin, mu), ref) < 1e-12
+    ef = bisect_prod(V, Vc, D, Gam, float(g["an_bisect_Nexp"]), 1e-6, -1e6)
+    assert abs(ef - float(g["an_bisect_fermi"])) < 1e-12
+    # grid integrals of the oracle against the closed form (in the non-orthogonal basis)
+    F, S, s1, s2, X = g["an_F"], g["an_S"], g["an_sig1"], g["an_sig2"], g["an_X"]
+
+    class Const:
+        def sigmaTot(self, E): return s1 + s2
+        def sigma(self, E, i): return (s1, s2)[i]
+    Eminf, Emin, mu = -1e6, -8.0, 0.2
+    Er, wr = oracle.real_axis_grid(Eminf, Emin, 600, 0.0)
+    Ec, wc = oracle.contour_grid(Emin, mu, 486, 0.0)
+    P = -np.imag(oracle.GrInt(F, S, Const(), Er, wr)) / np.pi + np.imag(oracle.GrInt(F, S, Const(), Ec, wc)) / np.pi
+    Pan = X @ g["an0_Pbar"] @ X
+    assert rel_fro(P, np.real(Pan)) < 2e-4             # the notebook reports ~4e-5 relative on currents
+    assert np.max(np.abs(np.imag(Pan))) < 1e-8 * np.max(np.abs(Pan))
+    assert rel_fro(oracle.density_analytic_from_system(F, S, s1, s2, Eminf, mu), Pan) < 1e-12
