@@ -257,3 +257,31 @@ def test_analytic_density_vs_reference_and_grid_integrals(golden_analytic, capsy
     assert rel_fro(P, np.real(Pan)) < 2e-4             # the notebook reports ~4e-5 relative on currents
     assert np.max(np.abs(np.imag(Pan))) < 1e-8 * np.max(np.abs(Pan))
     assert rel_fro(oracle.density_analytic_from_system(F, S, s1, s2, Eminf, mu), Pan) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["Au", "Au2"])
+def test_slater_koster_self_tests(name):
+    """The reference's own Slater-Koster checks (surfGBethe.py:649-829 / surfG3D.py:538-719 runAllTests),
+    applied to the drop-in's construct_sk_matrix: d-orbital angular functions along x, inversion symmetry
+    of the d-d block, p-d and d-d sigma / delta limits, s-p antisymmetry and conserved s-p magnitude."""
+    import os
+    from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix
+    _, _, Vd, Sd, _ = read_bethe_params(os.path.join(os.path.dirname(__file__), "golden", name))
+    for P in (Vd, Sd):
+        M = construct_sk_matrix(P, [1, 0, 0])
+        np.testing.assert_almost_equal(M[0, 8], 0.0)                                  # dxy along x
+        np.testing.assert_almost_equal(M[0, 7], np.sqrt(3) / 2 * P['sds'])            # dx2-y2 along x
+        np.testing.assert_almost_equal(M[0, 4], -0.5 * P['sds'])                      # dz2 along x
+        np.testing.assert_almost_equal(M[1, 8], 0.0)                                  # px-dxy along x
+        np.testing.assert_almost_equal(M[6, 6], P['ddd'])                             # dyz-dyz along x: pure delta
+        Mz = construct_sk_matrix(P, [0, 0, 1])
+        np.testing.assert_almost_equal(Mz[3, 4], P['pds'])                            # pz-dz2 along z: pure sigma
+        np.testing.assert_almost_equal(Mz[4, 4], P['dds'])                            # dz2-dz2 along z: pure sigma
+        d = 1 / np.sqrt(2)
+        np.testing.assert_array_almost_equal(construct_sk_matrix(P, [d, d, 0])[4:, 4:],
+                                             construct_sk_matrix(P, [-d, -d, 0])[4:, 4:])   # inversion, d-d block
+        for direction in ([0, 0, 1], [1, 0, 0], [0, 1, 0], [d, 0, d], [0, d, d], [d, d, 0]):
+            V = construct_sk_matrix(P, np.array(direction, dtype=float))
+            for i in range(1, 4):
+                assert abs(V[0, i] + V[i, 0]) < 1e-10                                  # s-p antisymmetry
+            assert abs(np.sqrt(V[0, 1] ** 2 + V[0, 2] ** 2 + V[0, 3] ** 2) - abs(P['sps'])) < 1e-10
