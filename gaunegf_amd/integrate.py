@@ -82,6 +82,78 @@ def _partial_gless(engine, g, E, w, ind):
     return acc
 
 
+# --------------------------------------------------------------------------- #
+# spin-polarised systems without spin mixing: blockdiag(alpha, beta) (scf.py:177-180)
+# --------------------------------------------------------------------------- #
+SPIN_BLOCK_SPLIT = True      # False: always work on the full 2N x 2N matrices, as the reference does
+
+
+class _NotBlockDiagonal(Exception):
+    pass
+
+
+class _SpinBlockView:
+    """One diagonal N x N block of a foreign 2N x 2N provider (reference protocol, host evaluated): every
+    matrix it hands out is checked to vanish outside the diagonal blocks."""
+    def __init__(self, g, N, sl, cache):
+        self.g, self.N, self.sl, self.cache = g, N, sl, cache
+
+    def _block(self, key, fn):
+        if key not in self.cache:
+            if len(self.cache) > 64:
+                self.cache.clear()
+            full = np.asarray(fn())
+            N = self.N
+            if full.shape != (2 * N, 2 * N) or np.any(full[:N, N:]) or np.any(full[N:, :N]):
+                raise _NotBlockDiagonal()
+            self.cache[key] = full
+        return self.cache[key][self.sl, self.sl]
+
+    def sigmaTot(self, E):
+        return self._block(("t", complex(E)), lambda: self.g.sigmaTot(E))
+
+    def sigma(self, E, i):
+        return self._block(("c", complex(E), i), lambda: self.g.sigma(E, i))
+
+
+def _spin_split(F, S, g):
+    """[(slice, F_block, S_block, g_block)] * 2 when F, S are exactly block diagonal 2N x 2N matrices and
+    the provider can serve the blocks separately; None otherwise.  Two N-sized solves then replace the
+    2N-sized one (a quarter of the flops); the result is the same up to rounding -- and exactly zero
+    between the blocks."""
+    n2 = F.shape[0]
+    if not SPIN_BLOCK_SPLIT or n2 % 2 or n2 < 4:
+        return None
+    N = n2 // 2
+    for M in (F, S):
+        if np.any(M[:N, N:]) or np.any(M[N:, :N]):
+            return None
+    sls = (slice(0, N), slice(N, n2))
+    if hasattr(g, "_negf_spin_split"):
+        halves = g._negf_spin_split(N)
+        if halves is None:
+            return None
+    elif hasattr(g, "_negf_lower"):
+        return None                                   # device-side provider defined on the 2N space
+    else:
+        cache = {}
+        halves = [_SpinBlockView(g, N, sl, cache) for sl in sls]
+    return [(sl, F[sl, sl], S[sl, sl], h) for sl, h in zip(sls, halves)]
+
+
+def _blockwise(F, S, g, call):
+    parts = _spin_split(F, S, g)
+    if parts is None:
+        return None
+    out = np.zeros(F.shape, dtype=np.complex128)
+    try:
+        for sl, Fb, Sb, gb in parts:
+            out[sl, sl] = call(np.ascontiguousarray(Fb), np.ascontiguousarray(Sb), gb)
+    except _NotBlockDiagonal:
+        return None
+    return out
+
+
 def _as_grid(Elist, weights):
     E = np.asarray(Elist)
     w = np.asarray(weights)
@@ -94,6 +166,9 @@ def GrInt(F, S, g, Elist, weights):
     S = np.asarray(S)
     E, w = _as_grid(Elist, weights)
     _check(F, S, E, w)
+    split = _blockwise(F, S, g, lambda Fb, Sb, gb: GrInt(Fb, Sb, gb, E, w))
+    if split is not None:
+        return split
     engine = get_engine()
     engine.set_system(F, S)
     E = np.ascontiguousarray(E.ravel(), dtype=np.complex128)
@@ -112,6 +187,9 @@ def GrLessInt(F, S, g, Elist, weights, ind=None):
     S = np.asarray(S)
     E, w = _as_grid(Elist, weights)
     _check(F, S, E, w)
+    split = _blockwise(F, S, g, lambda Fb, Sb, gb: GrLessInt(Fb, Sb, gb, E, w, ind))
+    if split is not None:
+        return split
     engine = get_engine()
     engine.set_system(F, S)
     E = np.ascontiguousarray(E.ravel(), dtype=np.complex128)

@@ -60,6 +60,24 @@ class surfGTest:
             self._lowered[key] = (engine, engine.sigma_const(mats))
         return self._lowered[key][1]
 
+    def _negf_spin_split(self, N):
+        """Two N x N constant providers for the diagonal spin blocks of a 2N x 2N system, or None when a
+        self-energy matrix couples the blocks (integrate.py's block-diagonal fast path)."""
+        if self.N != 2 * N:
+            return None
+        for sg in self.sig:
+            if np.any(sg[:N, N:]) or np.any(sg[N:, :N]):
+                return None
+        halves = []
+        for sl in (slice(0, N), slice(N, 2 * N)):
+            h = object.__new__(surfGTest)
+            h.F = np.asarray(self.F)[sl, sl]; h.S = np.asarray(self.S)[sl, sl]; h.N = N
+            h.indsList = self.indsList
+            h.sig = [np.ascontiguousarray(sg[sl, sl]) for sg in self.sig]
+            h._lowered = {}
+            halves.append(h)
+        return halves
+
     def _release(self):
         # handles are never reused by the library: freeing one that a change of the matrix dimension
         # already dropped is a no-op there

@@ -147,9 +147,33 @@ def _dos_kernel(E, F, S, sigma_total):
 # --------------------------------------------------------------------------- #
 # batched evaluation used by the front-ends
 # --------------------------------------------------------------------------- #
+SPIN_BLOCK_SPLIT = True      # False: always invert the full 2N x 2N matrix, as the reference does
 def _spinor_perm(N):
     # spinor [a0,b0,a1,b1,...] -> block [a0,a1,...,b0,b1,...] (transport.py:255)
     return np.concatenate([np.arange(0, 2 * N, 2), np.arange(1, 2 * N, 2)])
+
+
+def _spin_diagonal_blocks(F, S):
+    """(F_uu, S_uu, F_dd, S_dd) when the 2N x 2N block-form matrices are EXACTLY block diagonal (the layout
+    scf.py:177-180 builds for 'u' / 'ro': blockdiag(alpha, beta)), else None."""
+    n2 = F.shape[0]
+    if n2 % 2:
+        return None
+    N = n2 // 2
+    for M in (F, S):
+        if np.any(M[:N, N:]) or np.any(M[N:, :N]):
+            return None
+    return F[:N, :N], S[:N, :N], F[N:, N:], S[N:, N:]
+
+
+def _sigma_is_spin_expanded(sigma_calc, size):
+    """True when get_sigma* expand an N x N self-energy with kron(I2, .) for a 2N x 2N system
+    (transport.py:96-104): both spin blocks then see the same N x N self-energy."""
+    if sigma_calc.energy_dependent:
+        g = sigma_calc.sig1
+        n_sig = getattr(g, "F", None)
+        return n_sig is not None and 2 * np.asarray(n_sig).shape[0] == size
+    return 2 * SigmaCalculator._static(sigma_calc.sig1).shape[0] == size
 
 
 def _transmission_batch(F, S, sigma_calc, energies, spin):
@@ -161,6 +185,17 @@ def _transmission_batch(F, S, sigma_calc, energies, spin):
     S = np.asarray(S)
     eng = get_engine()
     size = F.shape[0]
+    if spin in ('u', 'ro') and SPIN_BLOCK_SPLIT and _sigma_is_spin_expanded(sigma_calc, size):
+        blocks = _spin_diagonal_blocks(F, S)
+        if blocks is not None:
+            # Spin-polarised system without spin mixing: G = blockdiag(G_uu, G_dd), so the four block traces
+            # of transport.py:166-177 are T_uu, 0, 0, T_dd with T_ss = Re Tr[G1 G_ss G2 G_ss^H] of the N x N
+            # spin block -- two N-sized solves instead of one 2N-sized one (a quarter of the flops).  The sum
+            # keeps the reference's order ((uu + ud) + du) + dd.
+            Tuu = _transmission_batch(blocks[0], blocks[1], sigma_calc, energies, 'r')
+            Tdd = _transmission_batch(blocks[2], blocks[3], sigma_calc, energies, 'r')
+            Ts = np.stack([Tuu, np.zeros_like(Tuu), np.zeros_like(Tuu), Tdd], axis=1)
+            return ((Ts[:, 0] + Ts[:, 1]) + Ts[:, 2]) + Ts[:, 3], Ts
     if spin == 'g':
         # shuffle everything to block form, as the reference does before its kernel
         perm = _spinor_perm(size // 2)

@@ -835,6 +835,50 @@ def test_config_C4_shape(engine):
     assert rel_fro(GrInt(F, S, g, Er[sub], wr[sub]), oracle.GrInt(F, S, Ref(), Er[sub], wr[sub])) < TOL
 
 
+def test_spin_block_diagonal_fast_path(engine):
+    """blockdiag(alpha, beta) systems (scf.py:177-180) run as two N-sized solves: GrInt / GrLessInt /
+    spin-'u' transmission must equal the full 2N x 2N path to 1e-12 and the oracle to 1e-8; a system WITH
+    spin mixing must not take the fast path."""
+    import gaunegf_amd.integrate as I
+    import gaunegf_amd.transport as T
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    from gaunegf_amd.surfGTester import surfGTest
+    N, nc = 40, 5
+    Fa, Sa = random_system(N, 71); Fb, _ = random_system(N, 72)
+    Z = np.zeros((N, N))
+    F = np.block([[Fa, Z], [Z, Fb]]); S = np.kron(np.eye(2), Sa)
+    inds, s1, s2 = const_sigma_pair(N, Sa, nc)
+    sig = [np.kron(np.eye(2), s1), np.kron(np.eye(2), s2)]
+
+    class G:                                             # foreign provider on the 2N space (host callback)
+        def sigma(self, E, i): return sig[i]
+        def sigmaTot(self, E): return sig[0] + sig[1]
+    inds2 = [list(inds[0]) + [N + i for i in inds[0]], list(inds[1]) + [N + i for i in inds[1]]]
+    g_const = surfGTest(F, S, inds2, -0.1j)              # device-side constant provider on the 2N space
+    E, w = oracle.bias_window_grid(-0.25, 0.25, 12, 300.0)
+    res = {}
+    for flag in (True, False):
+        I.SPIN_BLOCK_SPLIT = T.SPIN_BLOCK_SPLIT = flag
+        try:
+            res[flag] = (GrInt(F, S, G(), E, w), GrLessInt(F, S, G(), E, w, -1), GrInt(F, S, g_const, E, w),
+                         GrLessInt(F, S, g_const, E, w, 0),
+                         T.calculate_transmission(F, S, T.SigmaCalculator(s1, s2), np.real(E), spin='u'))
+        finally:
+            I.SPIN_BLOCK_SPLIT = T.SPIN_BLOCK_SPLIT = True
+    for k in range(4):
+        assert rel_fro(res[True][k], res[False][k]) < 1e-12, k
+        assert not np.any(res[True][k][:N, N:]) and not np.any(res[True][k][N:, :N])
+    assert np.allclose(res[True][4][0], res[False][4][0], rtol=1e-12, atol=1e-14)
+    assert np.allclose(res[True][4][1], res[False][4][1], rtol=1e-12, atol=1e-12)
+    assert rel_fro(res[True][0], oracle.GrInt(F, S, G(), E, w)) < TOL
+    assert rel_fro(res[True][1], oracle.GrLessInt(F, S, G(), E, w, -1)) < TOL
+    # spin mixing present: the fast path must step aside (result = full path = oracle)
+    C = np.zeros((N, N)); C[3, 7] = C[7, 3] = 0.05
+    Fm = np.block([[Fa, C], [C, Fb]])
+    assert I._spin_split(Fm, S, G()) is None
+    assert rel_fro(GrInt(Fm, S, G(), E, w), oracle.GrInt(Fm, S, G(), E, w)) < TOL
+
+
 def test_config_C5_shape(engine):
     """C5: spin-polarised 2 x 1000 block F/S (scf.py:177-180 layout), constant Sigma expanded with
     kron(I2, sigma) (transport.py:100), two energies of the qV = 0.5 V window at T = 300 K:
