@@ -632,19 +632,17 @@ void gj_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, i
 
 // which configuration serves dimension n: 0 = none.  The Q snapshot needs NB*n <= n*n.
 using CfgSplit = GjCfg<32, 2, 1, 8, 12>;   // n <= 256: panel 32, a row split over two lanes, 8 + 4 waves
-using CfgMid = GjCfg<16, 1, 1, 8, 12>;     // n <= 512: panel 16, 8 + 4 waves
 
 int gj_pick(int n)
 {
     if (n < 32) return 0;                               // small matrices: the unblocked kernel
     if (gj_fits<CfgSplit>(n)) return 1;
-    if (gj_fits<CfgMid>(n)) return 2;
     return 0;
 }
 
 
 // ======================================================================================
-// Large matrices (384 <= n <= 8192): the same in-place, implicit-pivot Gauss-Jordan reduction,
+// Large matrices (257 <= n <= 8192): the same in-place, implicit-pivot Gauss-Jordan reduction,
 // blocked at TWO levels across kernels.  For each window of WIN = 64 columns:
 //   gj_window_kernel  (one workgroup per matrix): factors the n x 64 block column in
 //       sub-panels of NBI columns with the register-strip pivot steps above and applies
@@ -733,37 +731,72 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             qwin[t] = (k < kw && c0 + j < n && j < cw) ? W[(size_t)pivrow[k0 + k] * n + c0 + j] : cmake(0.0, 0.0);
         }
         __syncthreads();
-        // ---- apply the sub-panel transform to the other window columns (in place)
-        for (int item = wave; item < tiles * (wt1 - wt0); item += PW) {
-            const int ti = item / (wt1 - wt0), tj = wt0 + item % (wt1 - wt0);
-            const int col = tj * 16 + fi;
-            const bool col_ok = col < n && col >= c0 && col < c0 + cw;
-            const bool col_store = col_ok && !(col >= k0 && col < k0 + kw);
-            d4 accr = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
+        // ---- apply the sub-panel transform to the other window columns (in place).  A wave takes whole
+        // row tiles: the P operand (the sub-panel's columns of the 16 rows) and the rows' pivot flags are
+        // fetched once per row tile and serve all column tiles of the window; every load is issued up
+        // front on clamped addresses (selects afterwards, no branch between a load and its MFMA) -- the
+        // operands come from L2 / HBM, and a dependent chain of such loads per tile was what this phase
+        // spent its time on.
+        constexpr int WT = WIN / 16;                                 // column tiles of a full window
+        for (int ti = wave; ti < tiles; ti += PW) {
+            const int prow = min(ti * 16 + fi, n - 1);
+            cplx pa[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pa[ks] = W[(size_t)prow * n + min(k0 + ks * 4 + fk, n - 1)];   // k >= kw pairs with Q == 0
+            bool keep[4];
+            const cplx* crow[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                if (i < n && col_ok) {
-                    const int cf = colof[i];
-                    if (!(cf >= k0 && cf < k0 + kw)) { const cplx v = W[(size_t)i * n + col]; accr[r] = v.x; acci[r] = v.y; }
+                const int i = min(ti * 16 + fk + 4 * r, n - 1);
+                const int cf = colof[i];
+                keep[r] = !(cf >= k0 && cf < k0 + kw);
+                crow[r] = W + (size_t)i * n;
+            }
+            // the C tiles of all column tiles at once where the register strips leave room (<= 2 rows per
+            // thread), tile by tile otherwise
+            constexpr int CB = RPT <= 2 ? WT : 1;
+            cplx cv[CB][4];
+            if (CB == WT) {
+#pragma unroll
+                for (int t = 0; t < CB; ++t) {
+                    const int colc = min(c0 + t * 16 + fi, n - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[t][r] = crow[r][colc];
                 }
             }
-            const int prow = ti * 16 + fi;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int k = ks * 4 + fk;
-                cplx pa = cmake(0.0, 0.0), qb = cmake(0.0, 0.0);
-                if (prow < n && k < kw) pa = W[(size_t)prow * n + k0 + k];
-                if (k < kw && col_ok) qb = qwin[k * WIN + (col - c0)];
-                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qb.x, accr, 0, 0, 0);
-                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qb.y, accr, 0, 0, 0);
-                acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qb.y, acci, 0, 0, 0);
-                acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qb.x, acci, 0, 0, 0);
-            }
+            for (int t = 0; t < WT; ++t) {
+                if (t < wt1 - wt0) {                                 // uniform: a narrow last window has fewer tiles
+                    const int col = c0 + t * 16 + fi;
+                    const bool col_store = col < n && col < c0 + cw && !(col >= k0 && col < k0 + kw);
+                    if (CB == 1) {
+                        const int colc = min(col, n - 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fk + 4 * r;
-                if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                        for (int r = 0; r < 4; ++r) cv[0][r] = crow[r][colc];
+                    }
+                    d4 accr, acci;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const cplx c = cv[CB == WT ? t : 0][r];
+                        accr[r] = keep[r] ? c.x : 0.0; acci[r] = keep[r] ? c.y : 0.0;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        // (zero outside the sub-panel / window; sub-panels narrower than a k-step have no such row)
+                        const int kq = ks * 4 + fk;
+                        cplx qb = qwin[(NBI % 4 == 0 ? kq : min(kq, NBI - 1)) * WIN + t * 16 + fi];
+                        if (NBI % 4 != 0 && kq >= NBI) qb = cmake(0.0, 0.0);
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.x, accr, 0, 0, 0);
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, -qb.y, accr, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.y, acci, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.x, acci, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = ti * 16 + fk + 4 * r;
+                        if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                    }
+                }
             }
         }
     }
@@ -936,15 +969,14 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // Returns true: the result is in B.
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
 {
-    // single-workgroup kernel below 384 rows (measured cross-over with the windowed path on
-    // MI355X: 300 -> 17.7 vs 24.4 ms, 400 -> 38.5 vs 34.8 ms per 1000 matrices); NEGF_GJ_LARGE_MIN
-    // moves the switch-over
+    // single-workgroup kernel up to 256 rows (its 32-column panel configuration); above, the windowed
+    // path with 16-column sub-panels is faster (measured on MI355X, ms per 1000 matrices: n = 260 9.3 vs
+    // 9.1, 300 13.3 vs 11.1, 340 20.5 vs 17.3, 370 28.5 vs 20.1); NEGF_GJ_LARGE_MIN moves the switch-over
     static int large_min = -1;
-    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 384; }
+    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 257; }
     if (n < large_min)
     switch (gj_pick(n)) {
     case 1: gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true;
-    case 2: gj_launch<CfgMid>(st, n, nb, A, B, stride, info); return true;
     default: break;
     }
     // sub-panels of 16 columns up to n = 1024 (measured on MI355X, 1000 matrices: n = 500 46.2 -> 41.1 ms,

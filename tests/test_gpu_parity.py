@@ -49,7 +49,7 @@ def test_library_is_loaded_in_process():
                          [(n, 2) for n in (257, 300, 383, 384, 500, 512, 513, 600, 1030)])
 def test_G_of_E_per_energy(engine, N, algo):
     """G(E) = solve(E S - F - Sigma, I) for every energy: unblocked kernel (algo 1), blocked
-    MFMA kernels (algo 2: panel 32 up to n=256, panel 16 up to 383, two-level windowed above)."""
+    MFMA kernels (algo 2: one workgroup per matrix with a 32-column panel up to n=256, two-level windowed above)."""
     from gaunegf_amd.integrate import GrBatch
     F, S, g_dev, g_ref = _const_provider(N, 100 + N)
     E = np.concatenate([np.linspace(-3, 3, 9), np.array([0.3 + 0.5j, -1.2 + 2j, 0.05 + 1e-3j])])
