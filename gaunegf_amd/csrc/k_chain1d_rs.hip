@@ -39,6 +39,9 @@ namespace {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
 constexpr int RS_NB = 16;                // panel width of the small inverse = one column tile
+#ifndef RS_PRIO
+#define RS_PRIO 1
+#endif
 
 struct ChainRsArgs {
     const cplx *alpha, *Salpha, *beta, *Sbeta, *tau, *Stau;   // concatenated per contact
@@ -49,6 +52,7 @@ struct ChainRsArgs {
     int max_iter, force_iters;
     cplx* gold;                      // [workgroups][KS][256] lane-private copies of the iterate (GOLD_GLOBAL kernels)
     int gold_lds_off, gold_lds_slots; // the first slots of a lane's copy live in LDS at this element offset
+    const int* order;                // launch slot -> job (energy * n_contacts + contact), longest jobs first; or null
     unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
 };
 
@@ -261,7 +265,11 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
         }
         if (has_next && wave == fw) {
             if (st && lane == 0) st[16 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
+            // the factoring wave is its workgroup's critical path (the others wait for it at the barrier):
+            // it goes first when it shares its SIMD's issue slots with waves of the other workgroups
+            if (RS_PRIO) __builtin_amdgcn_s_setprio(3);
             rs_factor<P>(n, W, pivrow, colof, rowline, n0, nw, lane);
+            if (RS_PRIO) __builtin_amdgcn_s_setprio(0);
             if (st && lane == 0) st[17 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
         }
         stamp();
@@ -286,7 +294,12 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     __shared__ int pivrow[64], colof[64];
     __shared__ cplx rowline[RS_NB];                     // pivot row of the column step being factored
 
-    const int c = blockIdx.x, b = blockIdx.y;
+    // job of this launch slot: in launch order, or -- when the provider has seen this grid before -- in
+    // the order of decreasing sweep counts of the previous evaluation (the jobs differ by up to 20x in
+    // length; started longest first, the last workgroups of the grid do not leave the chip idle)
+    const int slot = blockIdx.y * gridDim.x + blockIdx.x;
+    const int job = a.order ? a.order[slot] : slot;
+    const int c = job % a.n_contacts, b = job / a.n_contacts;
     const int n = a.nc[c];
     const int off = a.blk_off[c];
     cplx* Ws = reinterpret_cast<cplx*>(smem_raw);       // [16*T16][P] (+ slack): g (start of a sweep), T, M, the reduced M
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // of the work matrix itself, which only feed discarded output rows of the padded tiles and may hold any
     // finite values.  The other slots: global scratch [slot][thread] (coalesced); with the LDS part taken
     // off, the scratch of the workgroups of an XCD fits its 4 MB L2 and is rewritten there sweep after sweep.
-    cplx* gold_g = GOLD_GLOBAL ? a.gold + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KS) * RS_THREADS + tid : nullptr;
+    cplx* gold_g = GOLD_GLOBAL ? a.gold + ((size_t)slot * KS) * RS_THREADS + tid : nullptr;
     cplx* gold_l = Ws + a.gold_lds_off + fk * n + wave * 16 + fi;
     const int lds_slots = GOLD_GLOBAL ? a.gold_lds_slots : KS;
 
@@ -473,7 +486,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     int count = 0;
     bool first = true, final_pass = false;
     while (true) {
-        unsigned long long* st = (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && count == 10) ? a.stamps : nullptr;
+        unsigned long long* st = (a.stamps && job == 0 && count == 10) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
         rs_inverse<T16, P>(n, Ws, pivrow, colof, rowline, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
         if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
@@ -528,7 +541,42 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     }
 }
 
+// order[0..count) = job indices by decreasing sweep count (ties: increasing index): one workgroup, bitonic
+// sort of the packed keys in LDS.  count <= RS_ORDER_MAX.
+constexpr int RS_ORDER_MAX = 16384;
+__global__ __launch_bounds__(1024) void chain1d_order_kernel(const int* __restrict__ iters, int count, int* __restrict__ order)
+{
+    extern __shared__ int keys[];
+    int np2 = 1;
+    while (np2 < count) np2 <<= 1;
+    for (int t = threadIdx.x; t < np2; t += blockDim.x)
+        keys[t] = t < count ? iters[t] * RS_ORDER_MAX + (RS_ORDER_MAX - 1 - t) : -1;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < np2; t += blockDim.x) {
+                const int u = t ^ j;
+                if (u > t) {
+                    const bool desc = (t & k) == 0;
+                    const int a = keys[t], b = keys[u];
+                    if (desc ? a < b : a > b) { keys[t] = b; keys[u] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int t = threadIdx.x; t < count; t += blockDim.x) order[t] = RS_ORDER_MAX - 1 - (keys[t] % RS_ORDER_MAX);
+}
+
 }  // namespace
+
+bool chain1d_order_supported(int count) { return count > 0 && count <= RS_ORDER_MAX; }
+
+void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order)
+{
+    int np2 = 1;
+    while (np2 < count) np2 <<= 1;
+    hipLaunchKernelGGL(chain1d_order_kernel, dim3(1), dim3(1024), (size_t)np2 * sizeof(int), st, iters, count, order);
+}
 
 bool chain1d_lds_supported(int nc_max) { return nc_max <= 64; }
 
@@ -570,9 +618,10 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
 }  // namespace
 
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
-                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch)
+                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order)
 {
     ChainRsArgs a;
+    a.order = order;
     a.alpha = p.d_alpha; a.Salpha = p.d_Salpha; a.beta = p.d_beta; a.Sbeta = p.d_Sbeta;
     a.tau = p.d_tau; a.Stau = p.d_Stau;
     a.nc = d_nc; a.blk_off = d_blk_off;

@@ -82,7 +82,7 @@ void free_provider(SigmaProvider* p)
     dev_free(p->d_tau); dev_free(p->d_Stau);
     dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
     dev_free(p->d_H); dev_free(p->d_Slist); dev_free(p->d_Vlist); dev_free(p->d_xi);
-    dev_free(p->d_pre_tot); dev_free(p->d_pre_c);
+    dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order);
     delete p;
 }
 
@@ -224,7 +224,24 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                 if (rc) return rc;
                 c->scratch_cap = need;
             }
-            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch);
+            // jobs in the order of decreasing sweep counts of the previous evaluation of a grid of this size
+            // (Fermi searches and SCF cycles evaluate the same grids over and over); afterwards the order
+            // for the next evaluation is derived from this one's counts, on the stream, without a host sync
+            const int jobs = nb * p->n_contacts;
+            const bool can_order = p->force_iters < 0 && iters && chain1d_order_supported(jobs);
+            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch,
+                               (can_order && p->order_n == jobs) ? p->d_order : nullptr);
+            if (can_order) {
+                if (jobs > p->order_cap) {
+                    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+                    dev_free(p->d_order); p->order_cap = 0; p->order_n = 0;
+                    int rc = dev_alloc(&p->d_order, (size_t)jobs);
+                    if (rc) return rc;
+                    p->order_cap = jobs;
+                }
+                launch_chain1d_order(c->stream, iters, jobs, p->d_order);
+                p->order_n = jobs;
+            }
             return NEGF_OK;
         }
         const size_t per = chain1d_scratch_per_wg(p->nc_max);

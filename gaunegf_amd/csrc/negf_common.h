@@ -86,6 +86,9 @@ struct SigmaProvider {
          *d_tau = nullptr, *d_Stau = nullptr;
     double eta = 0, conv = 0, relFactor = 0, mix = 0;
     int max_iter = 0, force_iters = -1;
+    // job order learned from the previous evaluation of a grid of order_n jobs (chain kernel)
+    int* d_order = nullptr;
+    int order_n = 0, order_cap = 0;
     // BETHE
     std::vector<int> n_atoms;      // atoms per contact
     int* d_atom_orbs = nullptr;    // [total_atoms][9]
@@ -224,8 +227,12 @@ bool chain1d_lds_supported(int nc_max);
 // gold_scratch: chain1d_lds_scratch_elems() complex values of lane-private scratch (may be null:
 // the kernel then keeps the old iterate in LDS at a lower occupancy)
 size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb);
+// order: launch slot -> job (energy * n_contacts + contact) or null for launch order
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
-                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch);
+                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order);
+// order[0..count) = jobs by decreasing sweep count of the evaluation that just ran (iters[count])
+bool chain1d_order_supported(int count);
+void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order);
 
 // Bethe lattice: one workgroup per (energy, contact); writes per-atom 9x9 blocks
 void launch_bethe(hipStream_t st, const SigmaProvider& p, int nb, const cplx* E, cplx* blk,

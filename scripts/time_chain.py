@@ -5,9 +5,9 @@ sys.path.insert(0, '/root/repo')
 from scripts.bench_configs import _c3_system
 from gaunegf_amd.engine import get_engine
 F, S, g, ref = _c3_system()
-E = np.linspace(-2, 2, int(sys.argv[1]) if len(sys.argv) > 1 else 384)
+E = np.linspace(-2, 2, int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 384)
 eng = get_engine()
-g.sigma_batch(E[:8])
+g.sigma_batch(E[:8]); g.sigma_batch(E) if "--warm" in sys.argv else None
 eng.profile(True); eng.profile_reset()
 t0 = time.perf_counter(); sig, it, cv = g.sigma_batch(E); t = time.perf_counter() - t0
 ms, n = eng.profile_read("chain1d")
