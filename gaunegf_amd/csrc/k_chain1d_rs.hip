@@ -226,11 +226,58 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
     }
 }
 
+// ---- the look-ahead column tile (tile sgi+1, factored next) is the one update on the critical path of a
+// stage: it is shared by the four waves, one row tile each.  Every wave reads the Q fragment first; the
+// caller puts a barrier between load and update (a wave writes rows that are pivot rows of the others'
+// fragment) and one after the update.
+template <int P>
+__device__ __forceinline__ void rs_lookahead_load(const cplx* W, const int* pivrow, int tj, int p0, int pw, int lane,
+                                                  cplx (&qf)[RS_NB / 4])
+{
+    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < RS_NB / 4; ++ks) {
+        const int k = ks * 4 + fk;
+        const cplx v = W[pivrow[p0 + k] * P + tj * 16 + fi];
+        const bool ok = k < pw;
+        qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void rs_lookahead_update(int n, cplx* W, const int* colof, int ti, int tj, int p0, int pw,
+                                                    int lane, const cplx (&qf)[RS_NB / 4])
+{
+    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+    const int col = tj * 16 + fi;
+    cplx* cbase = W + (ti * 16 + fk) * P + col;
+    const cplx* pbase = W + (ti * 16 + fi) * P + p0 + fk;
+    cplx cv[4], pa[RS_NB / 4];
+    int cf[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cf[r] = colof[ti * 16 + fk + 4 * r]; cv[r] = cbase[4 * r * P]; }
+#pragma unroll
+    for (int ks = 0; ks < RS_NB / 4; ++ks) pa[ks] = pbase[ks * 4];
+    d4 accr, acci;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool keep = !(cf[r] >= p0 && cf[r] < p0 + pw);
+        accr[r] = keep ? cv[r].x : 0.0; acci[r] = keep ? cv[r].y : 0.0;
+    }
+#pragma unroll
+    for (int ks = 0; ks < RS_NB / 4; ++ks) zmfma(accr, acci, pa[ks], qf[ks]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ti * 16 + fk + 4 * r;
+        if (i < n && col < n) cbase[4 * r * P] = cmake(accr[r], acci[r]);
+    }
+}
+
 // In-place blocked Gauss-Jordan reduction of the n x n matrix W (LDS, pitch P) with implicit
 // pivoting.  On return  inv[i][j] = W[pivrow[i]][colof[j]].  All 256 threads call it; colof[] must be
-// -1 and visible (a barrier since it was reset).  One barrier per stage: at stage s the wave that
-// factors panel s+1 first applies panel s to that column tile, then factors it, while the other waves
-// apply panel s to the remaining column tiles (one owner per column tile).
+// -1 and visible (a barrier since it was reset).  Stage s: all waves apply panel s to the column tile of
+// panel s+1 (one row tile each, two barriers), then one wave factors panel s+1 while the other waves apply
+// panel s to the remaining column tiles (one owner per column tile, no barrier), one barrier at the end.
 template <int T16, int P>
 __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, cplx* rowline, int tid,
                                            unsigned long long* st = nullptr)
@@ -244,18 +291,25 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
         const int p0 = has_cur ? sgi * RS_NB : 0, pw = has_cur ? min(RS_NB, n - p0) : 0;
         const int n0 = (sgi + 1) * RS_NB, nw = has_next ? min(RS_NB, n - n0) : 0;
         const int fw = (sgi + 1) & (RS_WAVES - 1);              // the wave that factors panel sgi+1
+        if (has_cur && has_next) {
+            // the look-ahead column tile, one row tile per wave (T16 <= 4 = number of waves)
+            cplx qf[RS_NB / 4];
+            rs_lookahead_load<P>(W, pivrow, sgi + 1, p0, pw, lane, qf);
+            __syncthreads();
+            if (wave < T16 && wave * 16 < n) rs_lookahead_update<P>(n, W, colof, wave, sgi + 1, p0, pw, lane, qf);
+            __syncthreads();
+        }
         if (has_cur) {
-            // column tiles other than the panel's own, one owner each: tile sgi+1 goes to the wave that
-            // factors it next, the others are dealt to the remaining waves (all four after the last panel)
+            // the other column tiles, one owner each (the owner reads its Q fragment before it writes): dealt
+            // to the three waves that do not factor, to all four after the last panel
             const int team = has_next ? RS_WAVES - 1 : RS_WAVES;
             const int me = has_next ? ((wave - fw - 1) & (RS_WAVES - 1)) : wave;
             int cnt = 0;
 #pragma unroll 1
             for (int tj = 0; tj < npanels; ++tj) {
-                if (tj == sgi) continue;
-                bool mine;
-                if (has_next && tj == sgi + 1) mine = wave == fw;
-                else { mine = (!has_next || wave != fw) && (cnt % team == me); ++cnt; }
+                if (tj == sgi || (has_next && tj == sgi + 1)) continue;
+                const bool mine = (!has_next || wave != fw) && (cnt % team == me);
+                ++cnt;
                 if (mine) {
                     // a narrow last panel (<= 4 columns) runs one k-step instead of four
                     if (pw <= 4) rs_update_col<T16, P, 1>(n, W, pivrow, colof, tj, p0, pw, lane);
