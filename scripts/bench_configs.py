@@ -191,42 +191,47 @@ def c4b():
 
 
 def c5():
+    """C5 through the drop-in API: the 2N x 2N spin-'u' system is block diagonal (scf.py:177-180), so
+    GrLessInt and the spin-block transmission run as two N = 1000 solves (integrate._spin_split,
+    transport._transmission_batch); the full 2N x 2N path is timed beside it (SPIN_BLOCK_SPLIT off)."""
+    import gaunegf_amd.integrate as I
+    import gaunegf_amd.transport as T
     N = 1000
     Fa, Sa = random_system(N, 5); Fb, _ = random_system(N, 6)
     F = np.block([[Fa, np.zeros((N, N))], [np.zeros((N, N)), Fb]]); S = np.kron(np.eye(2), Sa)
     nc = 30
-    s1 = formSigma(list(range(nc)), -0.1j, N, Sa); s2 = formSigma(list(range(N - nc, N)), -0.1j, N, Sa)
-    sig = [np.kron(np.eye(2), s1), np.kron(np.eye(2), s2)]
-
-    class G:                                              # constant provider on the 2N x 2N space
-        def __init__(self): self.sig = sig; self.F = F; self.S = S; self.indsList = [0, 1]
-        def sigma(self, E, i): return self.sig[i]
-        def sigmaTot(self, E): return self.sig[0] + self.sig[1]
-    eng = get_engine()
-    eng.set_system(F, S)
-    h = eng.sigma_const(sig)
-    M = 64
+    left = list(range(nc)); right = list(range(N - nc, N))
+    s1 = formSigma(left, -0.1j, N, Sa); s2 = formSigma(right, -0.1j, N, Sa)
+    inds2 = [left + [N + i for i in left], right + [N + i for i in right]]
+    g = surfGTest(F, S, inds2, -0.1j)                       # constant provider on the 2N space: kron(I2, sigma)
+    assert np.allclose(g.sig[0], np.kron(np.eye(2), s1))
+    ref = oracle.ConstSigma(F, S, inds2, -0.1j)
+    sc = SigmaCalculator(s1, s2)
+    M = 256
     E, w = oracle.bias_window_grid(-0.25, 0.25, M, 300.0)
-    out = {"config": "C5 (1 GPU share): 2 x 1000 spin-block F/S (2000 x 2000), qV=0.5 V window, T=300 K, "
-                     f"{M} of the 512 Legendre points"}
-    eng.gless_int(h, -1, E, w)          # warm-up: the workspace (192 MB per energy) is allocated here
-    t0 = time.perf_counter(); r = eng.gless_int(h, -1, E, w); t = time.perf_counter() - t0
-    out["GrLessInt_ind-1"] = {"gpu_s": t, "gpu_pts_per_s": M / t, "gpu_tflops": 24.0 * (2 * N) ** 3 * M / t / 1e12}
-    M2 = 256                                             # more energies in flight: the panel kernels fill the GPU
-    E2, w2 = oracle.bias_window_grid(-0.25, 0.25, M2, 300.0)
-    eng.gless_int(h, -1, E2, w2)        # warm-up incl. the 49 GB workspace allocation
-    t0 = time.perf_counter(); eng.gless_int(h, -1, E2, w2); t2 = time.perf_counter() - t0
-    out["GrLessInt_ind-1_256pts"] = {"gpu_s": t2, "gpu_pts_per_s": M2 / t2, "gpu_tflops": 24.0 * (2 * N) ** 3 * M2 / t2 / 1e12,
-                                     "batch_in_flight": eng.get_batch() if hasattr(eng, "get_batch") else None}
-    # transmission, spin 'u' blocks (transport.py:159-181) on the same 2N x 2N system
     Et = np.linspace(-0.25, 0.25, M)
-    eng.transmission(h, 0, 1, Et, spin_block=True)
-    t0 = time.perf_counter(); Tt, Ts = eng.transmission(h, 0, 1, Et, spin_block=True); t3 = time.perf_counter() - t0
-    out["transmission_spin_u"] = {"gpu_s": t3, "gpu_pts_per_s": M / t3}
+    out = {"config": f"C5 (1 GPU share): 2 x 1000 spin-block F/S (2000 x 2000), qV=0.5 V window, T=300 K, "
+                     f"{M} of the 512 Legendre points; drop-in API (host pointers, incl. PCIe)"}
+    for split in (True, False):
+        I.SPIN_BLOCK_SPLIT = T.SPIN_BLOCK_SPLIT = split
+        try:
+            tag = "two_N_solves" if split else "full_2N"
+            t, r = timed(lambda: GrLessInt(F, S, g, E, w, -1), reps=1)
+            t2, (Tt, Ts) = timed(lambda: calculate_transmission(F, S, sc, Et, spin='u'), reps=1)
+            out[tag] = {"GrLessInt_ind-1_s": t, "GrLessInt_pts_per_s": M / t,
+                        "GrLessInt_tflops_of_the_2N_problem": 24.0 * (2 * N) ** 3 * M / t / 1e12,
+                        "transmission_spin_u_s": t2, "transmission_pts_per_s": M / t2}
+            if split:
+                r_split, T_split = r, Tt
+            else:
+                out["split_vs_full_rel_fro"] = rel(r_split, r)
+                out["split_vs_full_T_max_rel"] = float(np.max(np.abs(T_split - Tt) / np.maximum(1e-300, np.abs(Tt))))
+        finally:
+            I.SPIN_BLOCK_SPLIT = T.SPIN_BLOCK_SPLIT = True
     sub = [0, M // 2]
-    rate, ro = cpu_rate(lambda: oracle.GrLessInt(F, S, G(), E[sub], w[sub], -1), len(sub))
-    out["GrLessInt_ind-1"]["cpu_pts_per_s"] = rate
-    out["GrLessInt_ind-1"]["rel_fro_vs_oracle_sample"] = rel(eng.gless_int(h, -1, E[sub], w[sub]), ro)
+    rate, ro = cpu_rate(lambda: oracle.GrLessInt(F, S, ref, E[sub], w[sub], -1), len(sub))
+    out["cpu_pts_per_s"] = rate
+    out["rel_fro_vs_oracle_sample"] = rel(GrLessInt(F, S, g, E[sub], w[sub], -1), ro)
     return out
 
 
