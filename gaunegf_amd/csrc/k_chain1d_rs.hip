@@ -42,6 +42,9 @@ constexpr int RS_NB = 16;                // panel width of the small inverse = o
 #ifndef RS_PRIO
 #define RS_PRIO 1
 #endif
+#ifndef RS_REMAINDER
+#define RS_REMAINDER 1
+#endif
 
 struct ChainRsArgs {
     const cplx *alpha, *Salpha, *beta, *Sbeta, *tau, *Stau;   // concatenated per contact
@@ -76,6 +79,36 @@ __device__ __forceinline__ unsigned rs_wave_max_u32(unsigned k)
     const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
     return ab > cd ? ab : cd;
 }
+
+// ---- remainder tiles.  n_c = 50 is three tiles of 16 and two more rows / columns; a fourth 16 x 16 tile for
+// them costs as much as a full one.  v_mfma_f64_4x4x4_4b_f64 has the operand maps of the 16x16x4 instruction
+// (A: lane l holds A[l&15][l>>4], B: B[l>>4][l&15]) and computes the four DIAGONAL 4 x 4 blocks of the
+// 16 x 16 product, D_b[i][j] at lane 16 i + 4 b + j, in a quarter of the time (probed on MI355X,
+// scripts/probe/mfma4x4_probe.hip).  Used in two ways when the last tile holds <= 4 rows / columns:
+//   row strip  (last ROW tile):    every 4-row block of the A operand is loaded with the SAME rows
+//              (row R0 + (l&3)); the B operand is the normal 16-column fragment.  D lane l holds element
+//              (R0 + (l>>4), C0 + (l&15)) -- exactly component r = 0 of the 16 x 16 C layout.
+//   column strip (last COLUMN tile): every 4-column block of the B operand holds the SAME columns
+//              (column C0 + (l&3)); the A operand is the normal 16-row fragment.  D lane l holds element
+//              (R0 + 4 ((l>>2)&3) + (l>>4), C0 + (l&3)).
+// Both leave their result in component 0 of the tile's accumulator.
+__device__ __forceinline__ void zmfma4(double& ar, double& ai, cplx pa, cplx qb)
+{
+    ar = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.x, qb.x, ar, 0, 0, 0);
+    ar = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.y, -qb.y, ar, 0, 0, 0);
+    ai = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.x, qb.y, ai, 0, 0, 0);
+    ai = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.y, qb.x, ai, 0, 0, 0);
+}
+// pa * conj(b)
+__device__ __forceinline__ void zmfma4_conjb(double& ar, double& ai, cplx pa, cplx b)
+{
+    ar = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.x, b.x, ar, 0, 0, 0);
+    ar = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.y, b.y, ar, 0, 0, 0);
+    ai = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.y, b.x, ai, 0, 0, 0);
+    ai = __builtin_amdgcn_mfma_f64_4x4x4f64(-pa.x, b.y, ai, 0, 0, 0);
+}
+#define RS_ZMFMA4(ACCR, ACCI, PA, QB) do { double r_ = (ACCR)[0], i_ = (ACCI)[0]; zmfma4(r_, i_, PA, QB); (ACCR)[0] = r_; (ACCI)[0] = i_; } while (0)
+#define RS_ZMFMA4C(ACCR, ACCI, PA, QB) do { double r_ = (ACCR)[0], i_ = (ACCI)[0]; zmfma4_conjb(r_, i_, PA, QB); (ACCR)[0] = r_; (ACCI)[0] = i_; } while (0)
 
 // Hide a loop-invariant value from the optimiser: without this LLVM hoists every (tile, k-step)
 // LDS address of the sweep out of the fixed-point loop -- hundreds of live address registers that
@@ -173,17 +206,15 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
     }
 }
 
-// ---- trailing update of column tile tj with panel [p0, p0+pw), in place, by the wave that owns the
-// column tile in this stage:   W[i][col] = (i pivot row of the panel ? 0 : W[i][col]) + P[i][:] Q[:][col]
-// The Q fragment (the panel's pivot rows in this column tile) is read into registers before the first
-// store, so the owner needs no snapshot of the pivot rows.
-template <int T16, int P, int NKS>
-__device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow, const int* colof,
-                                              int tj, int p0, int pw, int lane)
+// ---- trailing update with panel [p0, p0+pw), in place:
+//        W[i][col] = (i pivot row of the panel ? 0 : W[i][col]) + P[i][:] Q[:][col]
+// A Q fragment holds the panel's pivot rows in the columns of one column tile (B operand); for the
+// column-strip tile TR every 4-column block holds the same columns TR*16 + (l&3) (see zmfma4).
+template <int P, int NKS, int TR /* last tile when it is a remainder strip, else -1 */>
+__device__ __forceinline__ void rs_load_qf(const cplx* W, const int* pivrow, int tj, int p0, int pw, int fi, int fk,
+                                           cplx (&qf)[NKS])
 {
-    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
-    const int col = tj * 16 + fi;
-    cplx qf[NKS];
+    const int col = (TR >= 0 && tj == TR) ? TR * 16 + (fi & 3) : tj * 16 + fi;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int k = ks * 4 + fk;
@@ -191,6 +222,74 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
         const bool ok = k < pw;
         qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
     }
+}
+
+// one tile (ti, tj): a full 16 x 16 tile, or a row / column strip (one value per lane, corner: one block)
+template <int P, int NKS, int TR>
+__device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof, int ti, int tj, int p0, int pw,
+                                               int fi, int fk, const cplx (&qf)[NKS])
+{
+    const bool rowstrip = TR >= 0 && ti == TR, colstrip = TR >= 0 && tj == TR;
+    if (!rowstrip && !colstrip) {
+        cplx* cbase = W + (ti * 16 + fk) * P + tj * 16 + fi;
+        const cplx* pbase = W + (ti * 16 + fi) * P + p0 + fk;
+        cplx cv[4], pa[NKS];
+        int cf[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cf[r] = colof[ti * 16 + fk + 4 * r]; cv[r] = cbase[4 * r * P]; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) pa[ks] = pbase[ks * 4];
+        d4 accr, acci;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool keep = !(cf[r] >= p0 && cf[r] < p0 + pw);
+            accr[r] = keep ? cv[r].x : 0.0; acci[r] = keep ? cv[r].y : 0.0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) zmfma(accr, acci, pa[ks], qf[ks]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + fk + 4 * r;
+            if (i < n && tj * 16 + fi < n) cbase[4 * r * P] = cmake(accr[r], acci[r]);
+        }
+    } else {
+        const int row = rowstrip ? TR * 16 + fk : ti * 16 + 4 * (fi >> 2) + fk;
+        const int col = colstrip ? TR * 16 + (fi & 3) : tj * 16 + fi;
+        const bool mine = !(rowstrip && colstrip) || (fi >> 2) == 0;      // the corner block exists four times
+        const cplx* prow = W + (rowstrip ? TR * 16 + (fi & 3) : ti * 16 + fi) * P + p0 + fk;
+        cplx* cptr = W + row * P + col;
+        const int cf = colof[row];
+        const cplx cv = *cptr;
+        cplx pa[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) pa[ks] = prow[ks * 4];
+        const bool keep = !(cf >= p0 && cf < p0 + pw);
+        double ar = keep ? cv.x : 0.0, ai = keep ? cv.y : 0.0;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) zmfma4(ar, ai, pa[ks], qf[ks]);
+        if (mine && row < n && col < n) *cptr = cmake(ar, ai);
+    }
+}
+
+// column tile tj, all row tiles, by the wave that owns the column tile in this stage.  The Q fragment is read
+// into registers before the first store, so the owner needs no snapshot of the pivot rows.
+template <int T16, int P, int NKS, int TR>
+__device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow, const int* colof,
+                                              int tj, int p0, int pw, int lane)
+{
+    constexpr int FT = TR >= 0 ? TR : T16;                   // full row tiles
+    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+    cplx qf[NKS];
+    rs_load_qf<P, NKS, TR>(W, pivrow, tj, p0, pw, fi, fk, qf);
+    if (TR >= 0 && tj == TR) {                               // the column strip: every tile on the 4x4x4 instruction
+#pragma unroll
+        for (int ti = 0; ti < T16; ++ti) {
+            rs_update_tile<P, NKS, TR>(n, W, colof, ti, tj, p0, pw, fi, fk, qf);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    const int col = tj * 16 + fi;
     cplx* cbase = W + fk * P + col;                          // C tile element (ti*16 + fk + 4r, col)
     const cplx* pbase = W + fi * P + p0 + fk;                // P operand element (ti*16 + fi, p0 + ks*4 + fk)
     const int* cfb = colof + fk;
@@ -206,9 +305,9 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
     };
     fetch(0, 0);
 #pragma unroll
-    for (int ti = 0; ti < T16; ++ti) {
+    for (int ti = 0; ti < FT; ++ti) {
         const int s = ti & 1;
-        if (ti + 1 < T16) fetch(ti + 1, s ^ 1);
+        if (ti + 1 < FT) fetch(ti + 1, s ^ 1);
         d4 accr, acci;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -224,53 +323,7 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-
-// ---- the look-ahead column tile (tile sgi+1, factored next) is the one update on the critical path of a
-// stage: it is shared by the four waves, one row tile each.  Every wave reads the Q fragment first; the
-// caller puts a barrier between load and update (a wave writes rows that are pivot rows of the others'
-// fragment) and one after the update.
-template <int P>
-__device__ __forceinline__ void rs_lookahead_load(const cplx* W, const int* pivrow, int tj, int p0, int pw, int lane,
-                                                  cplx (&qf)[RS_NB / 4])
-{
-    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
-#pragma unroll
-    for (int ks = 0; ks < RS_NB / 4; ++ks) {
-        const int k = ks * 4 + fk;
-        const cplx v = W[pivrow[p0 + k] * P + tj * 16 + fi];
-        const bool ok = k < pw;
-        qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
-    }
-}
-
-template <int P>
-__device__ __forceinline__ void rs_lookahead_update(int n, cplx* W, const int* colof, int ti, int tj, int p0, int pw,
-                                                    int lane, const cplx (&qf)[RS_NB / 4])
-{
-    const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
-    const int col = tj * 16 + fi;
-    cplx* cbase = W + (ti * 16 + fk) * P + col;
-    const cplx* pbase = W + (ti * 16 + fi) * P + p0 + fk;
-    cplx cv[4], pa[RS_NB / 4];
-    int cf[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { cf[r] = colof[ti * 16 + fk + 4 * r]; cv[r] = cbase[4 * r * P]; }
-#pragma unroll
-    for (int ks = 0; ks < RS_NB / 4; ++ks) pa[ks] = pbase[ks * 4];
-    d4 accr, acci;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const bool keep = !(cf[r] >= p0 && cf[r] < p0 + pw);
-        accr[r] = keep ? cv[r].x : 0.0; acci[r] = keep ? cv[r].y : 0.0;
-    }
-#pragma unroll
-    for (int ks = 0; ks < RS_NB / 4; ++ks) zmfma(accr, acci, pa[ks], qf[ks]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = ti * 16 + fk + 4 * r;
-        if (i < n && col < n) cbase[4 * r * P] = cmake(accr[r], acci[r]);
-    }
+    if (TR >= 0) rs_update_tile<P, NKS, TR>(n, W, colof, TR, tj, p0, pw, fi, fk, qf);    // the row strip
 }
 
 // In-place blocked Gauss-Jordan reduction of the n x n matrix W (LDS, pitch P) with implicit
@@ -278,7 +331,7 @@ __device__ __forceinline__ void rs_lookahead_update(int n, cplx* W, const int* c
 // -1 and visible (a barrier since it was reset).  Stage s: all waves apply panel s to the column tile of
 // panel s+1 (one row tile each, two barriers), then one wave factors panel s+1 while the other waves apply
 // panel s to the remaining column tiles (one owner per column tile, no barrier), one barrier at the end.
-template <int T16, int P>
+template <int T16, int P, int TR>
 __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, cplx* rowline, int tid,
                                            unsigned long long* st = nullptr)
 {
@@ -293,10 +346,11 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
         const int fw = (sgi + 1) & (RS_WAVES - 1);              // the wave that factors panel sgi+1
         if (has_cur && has_next) {
             // the look-ahead column tile, one row tile per wave (T16 <= 4 = number of waves)
+            const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
             cplx qf[RS_NB / 4];
-            rs_lookahead_load<P>(W, pivrow, sgi + 1, p0, pw, lane, qf);
+            rs_load_qf<P, RS_NB / 4, TR>(W, pivrow, sgi + 1, p0, pw, fi, fk, qf);
             __syncthreads();
-            if (wave < T16 && wave * 16 < n) rs_lookahead_update<P>(n, W, colof, wave, sgi + 1, p0, pw, lane, qf);
+            if (wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, sgi + 1, p0, pw, fi, fk, qf);
             __syncthreads();
         }
         if (has_cur) {
@@ -312,8 +366,8 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
                 ++cnt;
                 if (mine) {
                     // a narrow last panel (<= 4 columns) runs one k-step instead of four
-                    if (pw <= 4) rs_update_col<T16, P, 1>(n, W, pivrow, colof, tj, p0, pw, lane);
-                    else rs_update_col<T16, P, RS_NB / 4>(n, W, pivrow, colof, tj, p0, pw, lane);
+                    if (pw <= 4) rs_update_col<T16, P, 1, TR>(n, W, pivrow, colof, tj, p0, pw, lane);
+                    else rs_update_col<T16, P, RS_NB / 4, TR>(n, W, pivrow, colof, tj, p0, pw, lane);
                 }
             }
         }
@@ -343,6 +397,9 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     constexpr int T16 = (P - 1 + 15) / 16;              // 16-row tiles per dimension
     constexpr int KS = (P + 3) / 4 < 4 * T16 ? (P + 3) / 4 : 4 * T16;   // k-steps of a full-width product (n <= P)
     constexpr int WELEMS = 16 * T16 * P + 16;           // 16*T16 rows and a few elements of slack behind the last one
+    constexpr int TR = T16 - 1;                         // the last tile
+    constexpr bool REM = RS_REMAINDER && T16 >= 2 && P - 16 * TR <= 4;   // ... holds <= 4 rows / columns: strips
+    constexpr int FT = REM ? TR : T16;                  // full 16 x 16 tiles per dimension
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ int flags[2 * RS_WAVES];                 // per wave: any(diff > conv), all(diff <= conv)
     __shared__ int pivrow[64], colof[64];
@@ -404,8 +461,10 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // Ws is zero / finite, output columns >= n are never stored.
     auto gemm_rowtile = [&](d4 (&accr)[T16], d4 (&acci)[T16]) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+        const bool strip_wave = REM && wave == TR;      // this wave's row tile is the row strip
         const cplx* bb = Ws + fk * P + fi;
-        const int irow = min(wave * 16 + fi, n - 1) * n;
+        const cplx* bb4 = Ws + fk * P + (fi & 3);       // column-strip B operand: column TR*16 + (l&3) in every block
+        const int irow = min(strip_wave ? TR * 16 + (fi & 3) : wave * 16 + fi, n - 1) * n;
         const cplx* sS = opS + irow; const cplx* sM = opM + irow;
         Stream q;
 #pragma unroll
@@ -419,9 +478,16 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                 if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
                 cplx qb[T16];
 #pragma unroll
-                for (int tj = 0; tj < T16; ++tj) qb[tj] = bb[ks * 4 * P + tj * 16];
+                for (int tj = 0; tj < FT; ++tj) qb[tj] = bb[ks * 4 * P + tj * 16];
+                if (REM) qb[TR] = strip_wave ? bb[ks * 4 * P + TR * 16] : bb4[ks * 4 * P + TR * 16];
+                if (strip_wave) {
 #pragma unroll
-                for (int tj = 0; tj < T16; ++tj) zmfma(accr[tj], acci[tj], pa, qb[tj]);
+                    for (int tj = 0; tj < T16; ++tj) RS_ZMFMA4(accr[tj], acci[tj], pa, qb[tj]);
+                } else {
+#pragma unroll
+                    for (int tj = 0; tj < FT; ++tj) zmfma(accr[tj], acci[tj], pa, qb[tj]);
+                    if (REM) RS_ZMFMA4(accr[TR], acci[TR], pa, qb[TR]);
+                }
             }
             // the LDS operands of the next k-step are not requested earlier than this: the register file
             // holds the accumulators and ONE set of streamed operands; the other workgroups of the CU
@@ -432,8 +498,10 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // wave w: acc[ti] = sum_k Ws[ti*16 + fi][k] * conj(Op[w*16 + fi][k])  (column tile w of  Ws Op^H)
     auto gemm_coltile = [&](d4 (&accr)[T16], d4 (&acci)[T16]) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+        const bool strip_wave = REM && wave == TR;      // this wave's column tile is the column strip
         const cplx* ab = Ws + fi * P + fk;
-        const int irow = min(wave * 16 + fi, n - 1) * n;
+        const cplx* ab4 = Ws + (fi & 3) * P + fk;       // row-strip A operand: row TR*16 + (l&3) in every block
+        const int irow = min(strip_wave ? TR * 16 + (fi & 3) : wave * 16 + fi, n - 1) * n;
         const cplx* sS = opS + irow; const cplx* sM = opM + irow;
         Stream q;
 #pragma unroll
@@ -447,30 +515,46 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                 if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
                 cplx pa[T16];
 #pragma unroll
-                for (int ti = 0; ti < T16; ++ti) pa[ti] = ab[ti * 16 * P + ks * 4];
+                for (int ti = 0; ti < FT; ++ti) pa[ti] = ab[ti * 16 * P + ks * 4];
+                if (REM) pa[TR] = ab4[TR * 16 * P + ks * 4];
                 // pa * conj(b)
+                if (strip_wave) {
 #pragma unroll
-                for (int ti = 0; ti < T16; ++ti) {
-                    accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].x, br.x, accr[ti], 0, 0, 0);
-                    accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.y, accr[ti], 0, 0, 0);
-                    acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.x, acci[ti], 0, 0, 0);
-                    acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ti].x, br.y, acci[ti], 0, 0, 0);
+                    for (int ti = 0; ti < T16; ++ti) RS_ZMFMA4C(accr[ti], acci[ti], pa[ti], br);
+                } else {
+#pragma unroll
+                    for (int ti = 0; ti < FT; ++ti) {
+                        accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].x, br.x, accr[ti], 0, 0, 0);
+                        accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.y, accr[ti], 0, 0, 0);
+                        acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.x, acci[ti], 0, 0, 0);
+                        acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ti].x, br.y, acci[ti], 0, 0, 0);
+                    }
+                    if (REM) RS_ZMFMA4C(accr[TR], acci[TR], pa[TR], br);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // Where a lane's accumulator values of tile (ti, tj) live: FULL and ROW-STRIP tiles use the 16 x 16 C layout
+    // (rows ti*16 + fk + 4r, column tj*16 + fi; a row strip only fills r = 0), a COLUMN-STRIP tile (tj == TR of a
+    // full row tile) holds one value per lane at (ti*16 + 4 (fi>>2) + fk, TR*16 + (fi&3)).
+    // f(i, j, re, im) is called for every element this lane holds.
+    auto for_tile = [&](int ti, int tj, const d4& vr, const d4& vi, int fi, int fk, auto f) __attribute__((always_inline)) {
+        if (REM && tj == TR && ti != TR) {
+            f(ti * 16 + 4 * (fi >> 2) + fk, TR * 16 + (fi & 3), vr[0], vi[0]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!(REM && ti == TR) || r == 0) f(ti * 16 + fk + 4 * r, tj * 16 + fi, vr[r], vi[r]);
+        }
+    };
     // store row tile `wave` held as accumulators (C layout: rows fk + 4r, column fi of tile tj)
     auto store_rowtile = [&](const d4 (&accr)[T16], const d4 (&acci)[T16]) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
-        cplx* cb = Ws + (wave * 16 + fk) * P + fi;
 #pragma unroll
         for (int tj = 0; tj < T16; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = wave * 16 + fk + 4 * r, j = tj * 16 + fi;
-                if (i < n && j < n) cb[4 * r * P + tj * 16] = cmake(accr[tj][r], acci[tj][r]);
-            }
+            for_tile(wave, tj, accr[tj], acci[tj], fi, fk,
+                     [&](int i, int j, double re, double im) { if (i < n && j < n) Ws[i * P + j] = cmake(re, im); });
     };
     // g_new[k][col] = W[pivrow[k]][colof[col]] for this lane's elements; first: g = g_new, else the
     // reference's mixing and stopping test (surfG1D.py:276-284).  Leaves g in Ws and in gold.
@@ -542,7 +626,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     while (true) {
         unsigned long long* st = (a.stamps && job == 0 && count == 10) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-        rs_inverse<T16, P>(n, Ws, pivrow, colof, rowline, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
+        rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
         if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
         gather_mix(first);
         if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
@@ -561,29 +645,23 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         if (st && tid == 0) st[3] = __builtin_amdgcn_s_memrealtime();
         // T B^H : column tile `wave`
         gemm_coltile(mr, mi);
-        const int fis = rs_opaque(lane & 15), fks = rs_opaque(lane >> 4), j = wave * 16 + fis;
+        const int fis = rs_opaque(lane & 15), fks = rs_opaque(lane >> 4);
         if (final_pass) {
             cplx* out = blk + (size_t)b * a.blk_stride + off;
 #pragma unroll
             for (int ti = 0; ti < T16; ++ti)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = ti * 16 + fks + 4 * r;
-                    if (i < n && j < n) out[i * n + j] = cmake(mr[ti][r], mi[ti][r]);
-                }
+                for_tile(ti, wave, mr[ti], mi[ti], fis, fks,
+                         [&](int i, int j, double re, double im) { if (i < n && j < n) out[i * n + j] = cmake(re, im); });
             break;
         }
         __syncthreads();
         // M = A - T B^H
-        cplx* mb = Ws + fks * P + j;
 #pragma unroll
         for (int ti = 0; ti < T16; ++ti) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = ti * 16 + fks + 4 * r;
+            for_tile(ti, wave, mr[ti], mi[ti], fis, fks, [&](int i, int j, double re, double im) {
                 const cplx av = Aat(i, j);
-                if (i < n && j < n) mb[(ti * 16 + 4 * r) * P] = cmake(av.x - mr[ti][r], av.y - mi[ti][r]);
-            }
+                if (i < n && j < n) Ws[i * P + j] = cmake(av.x - re, av.y - im);
+            });
             __builtin_amdgcn_sched_barrier(0);          // the A elements of one tile in flight, not of all
         }
         __syncthreads();
@@ -700,8 +778,10 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     if (n <= 16) RS_CASE(17); else RS_CASE(51);
 #else
     if (n <= 16) RS_CASE(17);
+    else if (n <= 19) RS_CASE(19);                // 16 + a remainder strip
     else if (n <= 25) RS_CASE(25);
     else if (n <= 32) RS_CASE(33);
+    else if (n <= 35) RS_CASE(35);                // 32 + a remainder strip
     else if (n <= 41) RS_CASE(41);
     else if (n <= 48) RS_CASE(49);
     else if (n <= 51) RS_CASE(51);

@@ -385,11 +385,11 @@ def test_compact_gamma_products_match_dense_and_oracle(engine):
             assert abs(T[0][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
 
 
-@pytest.mark.parametrize("nc", [4, 10, 20, 33, 48, 50, 64, 65, 80])
+@pytest.mark.parametrize("nc", [4, 10, 18, 20, 33, 48, 50, 51, 64, 65, 80])
 def test_chain1d_fixed_trip_count(engine, nc):
     """Same number of sweeps on both sides -> the iterate itself must agree.  n_c = 33/48 and 50/64
-    are the three- and four-tile LDS kernels (50 = BASELINE C3's lead, 64 with B outside LDS),
-    65 and 80 the global-scratch kernel for n_c > 64."""
+    are the three- and four-tile kernels (50 = BASELINE C3's lead); 18, 33, 50, 51 run their last tile as a
+    remainder strip on the 4x4x4 matrix instruction; 65 and 80 the global-scratch kernel for n_c > 64."""
     N = 3 * nc
     F, S, g_dev, g_ref = _chain_system(N, nc, 70 + nc, 1e-4)
     g_dev.force_iters = 40; g_ref.force_iters = 40
