@@ -647,12 +647,12 @@ int gj_pick(int n)
 //   gj_window_kernel  (one workgroup per matrix): factors the n x 64 block column in
 //       sub-panels of NBI columns with the register-strip pivot steps above and applies
 //       every sub-panel transform to the 64 window columns only (MFMA, operands L2-hot);
-//       afterwards the window holds the block column P' of the combined transform and the
-//       64 pivot rows are snapshotted as Q (their other columns are still untouched).
-//   gj_bigupdate_kernel (a 64 x 64 output block per workgroup, all other columns):
+//       afterwards the window holds the block column P' of the combined transform; the other
+//       columns of its 64 pivot rows (Q) are still untouched.
+//   gj_colupdate_kernel (one workgroup per block of 64 columns outside the window, all rows):
 //       W[i][J] = (i pivot row of this window ? 0 : W[i][J]) + P'[i][:] * Q[:][J]
-//       an LDS-tiled complex GEMM on the FP64 matrix cores with K = 64: 16 flop per byte of
-//       matrix traffic, i.e. compute-bound for n >~ 500.
+//       on the FP64 matrix cores with K = 64, Q in registers, P' streamed through LDS by LDS-DMA
+//       (details at the kernel).
 // pivrow / colof live in global memory between launches.  gj_gather_kernel forms
 // G[i][j] = W[pivrow[i]][colof[j]].
 // ======================================================================================
@@ -662,8 +662,9 @@ constexpr int PT = PW * 64;
 
 template <int NBI, int RPT>
 __global__ __launch_bounds__(PT) void gj_window_kernel(
-    int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB, size_t mat_stride,
-    int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw)
+    int n, cplx* __restrict__ bufA, size_t mat_stride,
+    int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw,
+    unsigned long long* __restrict__ stamps /* diagnostic (NEGF_GJ_STAMPS): workgroup 0, window 1; nullptr in production */)
 {
     using C = GjCfg<NBI, 1, RPT, PW, PW>;
     constexpr int S = NBI;
@@ -678,7 +679,6 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     cplx* W = bufA + (size_t)blockIdx.x * mat_stride;
-    cplx* X = bufB + (size_t)blockIdx.x * mat_stride;
     int* pivrow = piv_all + (size_t)blockIdx.x * 2 * n;
     int* colof = pivrow + n;
     int team_expect = 0;
@@ -690,9 +690,16 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
     const int tiles = (n + 15) >> 4;
     const int wt0 = c0 >> 4, wt1 = (c0 + cw + 15) >> 4;          // column tiles of the window
 
+    int sti = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if (stamps && blockIdx.x == 0 && tid == 0 && sti < 60) stamps[sti] = __builtin_amdgcn_s_memrealtime();
+        ++sti;
+    };
+    stamp();
     for (int k0 = c0; k0 < c0 + cw; k0 += NBI) {
         const int kw = min(NBI, c0 + cw - k0);
         __syncthreads();                 // previous window update (global stores) complete
+        stamp();                         // 1 + 5 s: sub-panel s starts
         // ---- strips of the sub-panel, pivot steps (all 8 waves form the panel team)
         cplx a[RPT][S];
         bool avail[RPT];
@@ -710,9 +717,11 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
         // the last two columns of a panel publish nothing into theirs)
         PanelCtx<C> ctx{a, avail, cand, slot, &bad_sh, pivrow, colof,
                                       &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, nullptr};
+            stamp();                     // strips loaded
             publish_candidate<C>(ctx, 0, 0, 0);
             team_sync<PW>(&team_ctr, team_expect, lane);
             PanelSteps<C, 0>::run(ctx);
+            stamp();                     // pivot steps done
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
@@ -725,12 +734,14 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             }
         }
         __syncthreads();                 // sub-panel columns and pivrow/colof (global) visible
+        stamp();                         // strips stored
         // ---- pivot rows of this sub-panel, window columns -> LDS
         for (int t = tid; t < NBI * WIN; t += PT) {
             const int k = t / WIN, j = t - k * WIN;
             qwin[t] = (k < kw && c0 + j < n && j < cw) ? W[(size_t)pivrow[k0 + k] * n + c0 + j] : cmake(0.0, 0.0);
         }
         __syncthreads();
+        stamp();                         // Q of the sub-panel staged
         // ---- apply the sub-panel transform to the other window columns (in place).  A wave takes whole
         // row tiles: the P operand (the sub-panel's columns of the 16 rows) and the rows' pivot flags are
         // fetched once per row tile and serve all column tiles of the window; every load is issued up
@@ -800,103 +811,149 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             }
         }
     }
+    stamp();                             // thread 0's share of the last update done
     __syncthreads();
-    // ---- Q snapshot for the big update: the cw pivot rows of this window, all columns
-    for (int k = wave; k < cw; k += PW) {
-        const cplx* srow = W + (size_t)pivrow[c0 + k] * n;
-        cplx* drow = X + (size_t)k * n;
-        for (int j = lane; j < n; j += 64) drow[j] = srow[j];
-    }
+    stamp();                             // all updates done
+    // (no Q snapshot: gj_colupdate_kernel reads the window's pivot rows in place)
     if (tid == 0 && bad_sh != 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad_sh;
 }
 
-// W[i][J] = (row i pivot of the window ? 0 : W[i][J]) + P'[i][0:cw) * Q[0:cw)[J]  for the column
-// blocks outside the window.  Workgroup = 512 threads = 8 waves, 64 x 64 output block, wave tile
-// 32 x 16 (2 x 1 MFMA tiles, 32 accumulator VGPRs), K tile 16 through LDS.  The product is
-// accumulated from ZERO and the old block is added at the end: its HBM loads are issued before the
-// last k-tile and never sit in front of the matrix pipe; the operand tile after the current one is
-// fetched into registers while the current one runs its MFMAs.
-constexpr int BU_THREADS = 512;
+// ---- Column-block big update.  One workgroup (512 threads, 8 waves, one per CU) OWNS a block of 64 columns
+// outside the window and applies the window to all of its rows:
+//     W[i][J] = (row i pivot of the window ? 0 : W[i][J]) + P'[i][0:cw) * Q[0:cw)[J]
+// * Q[:, J] -- the window's pivot rows in the block's columns -- is read IN PLACE into registers before the
+//   first store (16 x n_k fragments of the wave's column tile, 64 VGPRs): only this workgroup ever touches
+//   column block J, so the window kernel needs no Q snapshot (0.5 MB written and read back per matrix and
+//   window at n = 500) and the matrix-core loop has no B-operand traffic at all;
+// * the row blocks of 64 stream through: P'[I] (64 x cw) -> LDS (A operand), the old block C[I][J] -> the
+//   accumulators; the operands of row block I+1 are requested before row block I runs its 128 MFMAs per
+//   wave, so the L2 / HBM latency of the operands and of the old block is covered by matrix work (the
+//   64 x 64-tile-per-workgroup kernel this replaces paid it twice per tile: 22 -> 19.7 ms per 1000 matrices
+//   of n = 500 including the dropped snapshot; measured alone on MI355X: MFMA work 2.06 ms, loads + stores
+//   1.56 ms, together 2.61 ms per window);
+// * launch order is XCD-aware: workgroup L runs on XCD L % 8, and the column blocks of one matrix are
+//   consecutive slots of ONE XCD, so that they share P' in that XCD's L2.
+constexpr int CU_THREADS = 512;
+constexpr int CU_AP = 65;                         // odd pitch of the A tile in LDS: conflict-free fragment reads
 
-__global__ __launch_bounds__(BU_THREADS, 4) void gj_bigupdate_kernel(
-    int n, cplx* __restrict__ bufA, const cplx* __restrict__ bufB, size_t mat_stride,
-    const int* __restrict__ piv_all, int c0, int cw)
+__global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
+    int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cw)
 {
-    constexpr int BM = 64, BN = 64, BK = 16, AP = BK + 1, BP = BN + 1;
-    __shared__ cplx As[BM * AP];
-    __shared__ cplx Bs[BK * BP];
-    const int col0 = blockIdx.x * BN, row0 = blockIdx.y * BM;
-    if (col0 >= c0 && col0 < c0 + cw) return;                    // window columns: already final (uniform)
-    cplx* W = bufA + (size_t)blockIdx.z * mat_stride;
-    const cplx* Q = bufB + (size_t)blockIdx.z * mat_stride;
-    const int* colof = piv_all + (size_t)blockIdx.z * 2 * n + n;
+    __shared__ cplx As[2][64 * CU_AP];            // P'[I] of the current and of the next row block
+    __shared__ unsigned char pflag[8192];         // row is a pivot row of this window (its old content counts as zero)
+    const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = nblk - 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int m = (slot / per_mat) * 8 + xcd;
+    if (m >= nb) return;                                         // (uniform)
+    int jb = slot % per_mat;
+    if (jb >= jwin) ++jb;                                        // skip the window's own block
+    cplx* W = bufA + (size_t)m * mat_stride;
+    const int* pivrow = piv_all + (size_t)m * 2 * n;
+    const int* colof = pivrow + n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 2) * 32, wc = (wave & 3) * 16;
+    const int wr = (wave >> 2) * 32, wc = (wave & 3) * 16;       // wave tile 32 x 16 of the 64 x 64 block
     const int fi = lane & 15, fk = lane >> 4;
-    d4 accr[2], acci[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) { accr[a] = (d4){0, 0, 0, 0}; acci[a] = (d4){0, 0, 0, 0}; }
+    const int col = jb * 64 + wc + fi;
+    const bool col_ok = col < n;
+    const int colc = col_ok ? col : n - 1;
 
-    // staging: A tile 64 x 16 and B tile 16 x 64, two consecutive elements per thread each
-    const int lr = tid >> 3, lc = (tid & 7) * 2;                 // A: row lr, k lc..lc+1
-    const int br = tid >> 5, bc = (tid & 31) * 2;                // B: k br, cols bc..bc+1
-    cplx ra[2], rb[2];
-    auto fetch = [&](int k0) __attribute__((always_inline)) {
-        const int gi = row0 + lr, gk = k0 + br;
+    for (int i = tid; i < n; i += CU_THREADS) { const int c = colof[i]; pflag[i] = (c >= c0 && c < c0 + cw) ? 1 : 0; }
+    // Q fragments of this wave's column tile: B operand element (k = ks*4 + fk, col)
+    cplx qf[16];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int ak = k0 + lc + e, gj = col0 + bc + e;
-            ra[e] = (gi < n && ak < cw) ? W[(size_t)gi * n + c0 + ak] : cmake(0.0, 0.0);
-            rb[e] = (gk < cw && gj < n) ? Q[(size_t)gk * n + gj] : cmake(0.0, 0.0);
+    for (int ks = 0; ks < 16; ++ks) {
+        const int k = ks * 4 + fk;
+        const cplx v = W[(size_t)pivrow[c0 + min(k, cw - 1)] * n + colc];
+        const bool ok = (k < cw) & col_ok;
+        qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
+    }
+    // P'[I] (64 rows x 64 k) goes global -> LDS directly (global_load_lds_dwordx4: no register staging): a wave
+    // fills eight rows, one instruction per row -- lane = k, 1 KB contiguous in LDS (pitch 65 stays legal: no
+    // instruction crosses a row) and in global memory.  Lanes k >= cw and rows >= n re-read the last valid
+    // column / row: finite values that meet zero Q rows / feed discarded output rows.
+    const size_t a_lane = (size_t)c0 + min(lane, cw - 1);
+    auto fetch_a = [&](int ib, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = wave * 8 + j;
+            const cplx* src = W + (size_t)min(ib * 64 + row, n - 1) * n + a_lane;
+            // (asm: hipcc would drain a builtin LDS-DMA -- vmcnt(0) -- in front of the next ds_read of the OTHER
+            //  buffer; the completion of these loads is awaited by the vmcnt(0) of the barrier at the loop top)
+            const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)&As[buf][row * CU_AP]);   // wave-uniform -> SGPR
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
         }
     };
-    // the old block (zero for the pivot rows of this window), requested before the last k-tile
     cplx cv[2][4];
-    auto fetch_c = [&]() __attribute__((always_inline)) {
+    auto fetch_c = [&](int ib) __attribute__((always_inline)) {
+        const int r0 = ib * 64 + wr + fk;
+        const cplx* cbase = W + (size_t)min(r0, n - 1) * n + colc;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + fi;
-                const int gic = min(gi, n - 1), gjc = min(gj, n - 1);
-                const int cf = colof[gic];
-                const cplx v = W[(size_t)gic * n + gjc];
-                const bool z = cf >= c0 && cf < c0 + cw;
-                cv[a][r] = cmake(z ? 0.0 : v.x, z ? 0.0 : v.y);
+                const int di = a * 16 + 4 * r;                       // row r0 + di, clamped to the last row
+                cv[a][r] = cbase[(size_t)min(di, max(n - 1 - r0, 0)) * n];
             }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < cw; k0 += BK) {
+    fetch_a(0, 0);
+    fetch_c(0);
+    // Software pipeline over the row blocks (one barrier each).  At the top of iteration ib everything this
+    // wave has in flight is awaited: P'[ib] and C[ib] (requested an iteration ago, in front of 128 MFMAs) and
+    // the stores of block ib-2 (issued an iteration ago as well) -- the results of block ib-1 are still in
+    // registers and are stored only AFTER the requests for block ib+1, so that no wait ever sees a fresh store.
+    d4 sr[2], si[2];                      // results of the previous row block, not stored yet
+    auto store_block = [&](int ib) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) { As[lr * AP + lc + e] = ra[e]; Bs[br * BP + bc + e] = rb[e]; }
-        __syncthreads();
-        if (k0 + BK < cw) fetch(k0 + BK);
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int ks = 0; ks < BK; ks += 4) {
-            cplx af[2];
+            for (int r = 0; r < 4; ++r) {
+                const int gi = ib * 64 + wr + a * 16 + fk + 4 * r;
+                if (gi < n && col_ok) W[(size_t)gi * n + col] = cmake(sr[a][r], si[a][r]);
+            }
+    };
+    for (int ib = 0; ib < nblk; ++ib) {
+        const int buf = ib & 1;
+        d4 cr[2], ci[2];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of P'[ib] (not in hipcc's bookkeeping)
+        __syncthreads();                  // (vmcnt(0): the Q fragments too, before the first store to the block)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = As[(wr + a * 16 + fi) * AP + ks + fk];
-            const cplx bf = Bs[(ks + fk) * BP + wc + fi];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool z = pflag[min(ib * 64 + wr + a * 16 + fk + 4 * r, n - 1)] != 0;
+                cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].y;
+            }
+        if (ib + 1 < nblk) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
+        if (ib > 0) store_block(ib - 1);
+        const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
+        cplx af[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[0][a] = ab[a * 16 * CU_AP];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 16) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) af[cur ^ 1][a] = ab[a * 16 * CU_AP + (ks + 1) * 4];
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                accr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf.x, accr[a], 0, 0, 0);
-                accr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf.y, accr[a], 0, 0, 0);
-                acci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf.y, acci[a], 0, 0, 0);
-                acci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf.x, acci[a], 0, 0, 0);
+                cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x, qf[ks].x, cr[a], 0, 0, 0);
+                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x, qf[ks].y, ci[a], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[cur][a].y, qf[ks].y, cr[a], 0, 0, 0);
+                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].y, qf[ks].x, ci[a], 0, 0, 0);
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { sr[a] = cr[a]; si[a] = ci[a]; }
     }
-    // (requested after the loop: with the prefetch registers dead the kernel fits 128 VGPRs, two
-    //  workgroups per CU -- the other workgroup covers this latency)
-    fetch_c();
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gi = row0 + wr + a * 16 + fk + 4 * r, gj = col0 + wc + fi;
-            if (gi < n && gj < n) W[(size_t)gi * n + gj] = cmake(cv[a][r].x + accr[a][r], cv[a][r].y + acci[a][r]);
-        }
+    store_block(nblk - 1);
 }
 
 __global__ __launch_bounds__(256) void gj_gather_kernel(int n, const cplx* __restrict__ bufA,
@@ -937,16 +994,37 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
                                   (int)(100 * 1024));
         attr_set = true;
     }
+    static int want_stamps = -1;
+    static unsigned long long* d_stamps = nullptr;
+    if (want_stamps < 0) {
+        want_stamps = getenv("NEGF_GJ_STAMPS") ? 1 : 0;
+        if (want_stamps) { (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 64 * sizeof(unsigned long long)); }
+    }
     hipLaunchKernelGGL(gj_state_init_kernel, dim3(nb), dim3(256), 0, st, n, piv, info);
     const int nblk = (n + 63) / 64;
     for (int c0 = 0; c0 < n; c0 += WIN) {
         const int cw = min(WIN, n - c0);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, B, stride, piv, info, c0, cw);
-        hipLaunchKernelGGL(gj_bigupdate_kernel, dim3(nblk, nblk, nb), dim3(BU_THREADS), 0, st, n, A, B, stride,
-                           (const int*)piv, c0, cw);
+        hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, stride, piv, info, c0, cw,
+                           c0 == WIN ? d_stamps : (unsigned long long*)nullptr);
+        if (nblk > 1)
+            hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((nb + 7) / 8) * (nblk - 1)), dim3(CU_THREADS), 0, st,
+                               n, nb, A, stride, (const int*)piv, c0, cw);
     }
     hipLaunchKernelGGL(gj_gather_kernel, dim3(n, nb), dim3(256), 0, st, n, (const cplx*)A, B, stride,
                        (const int*)piv, (const int*)info);
+    if (d_stamps) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long h[64];
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        auto us = [&](int i) { return (double)(h[i] - h[0]) / 100.0; };
+        fprintf(stderr, "[gj window stamps] n=%d window 1, workgroup 0 (us):", n);
+        const int nsub = (WIN + NBI - 1) / NBI;
+        for (int sp = 0; sp < nsub && 1 + 5 * sp + 4 < 60; ++sp)
+            fprintf(stderr, " | sub %d: start %.1f loaded %.1f pivots %.1f stored %.1f q %.1f", sp, us(1 + 5 * sp), us(2 + 5 * sp),
+                    us(3 + 5 * sp), us(4 + 5 * sp), us(5 + 5 * sp));
+        if (1 + 5 * nsub + 2 < 60)
+            fprintf(stderr, " | upd(t0) %.1f upd(all) %.1f\n", us(1 + 5 * nsub), us(2 + 5 * nsub));
+    }
 }
 
 int gj_large_pick(int n)

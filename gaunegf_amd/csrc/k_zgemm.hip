@@ -132,6 +132,115 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
             }
 }
 
+// ---- flexible-block version for shapes the 64 x 64 block tile pads badly (n = 200: 13 tiles of 16 per
+// dimension fill 4 x 4 blocks of 64 only to 66 %, and an edge block costs almost what a full one does:
+// measured 34 TF at n = 200 against 53 TF at n = 192).  A block covers tm x tn sub-tiles of 16 x 16 with
+// tm, tn <= 7, the sub-tile counts of the blocks of a dimension differ by at most one (13 -> 7 + 6), so no
+// block is mostly padding; the block's sub-tiles are dealt to 8 waves, up to 7 each (112 accumulator VGPRs),
+// every sub-tile reads its own A and B fragment from LDS (one read each per 4 MFMAs).
+static constexpr int ZF_MAXT = 7, ZF_THREADS = 512, ZF_WAVES = 8;
+static constexpr int ZF_ROWS = ZF_MAXT * 16;                    // 112
+static constexpr int ZF_APITCH = ZG_BK + 1, ZF_BPITCH = ZF_ROWS + 1;
+
+__host__ __device__ inline void zf_block_range(int tiles, int nblk, int b, int* t0, int* tn)
+{
+    const int base = tiles / nblk, rem = tiles % nblk;
+    *t0 = b * base + (b < rem ? b : rem);
+    *tn = base + (b < rem ? 1 : 0);
+}
+
+__global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
+    int M, int N, int K, int nbm, int nbn,
+    const cplx* __restrict__ Aall, int lda, size_t strideA,
+    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
+    cplx* __restrict__ Call, int ldc, size_t strideC)
+{
+    __shared__ cplx As[ZF_ROWS * ZF_APITCH];     // As[i][k]
+    __shared__ cplx Bs[ZG_BK * ZF_BPITCH];       // Bs[k][j]  (already op()'ed)
+    const int b = blockIdx.z;
+    const cplx* A = Aall + (size_t)b * strideA;
+    const cplx* B = Ball + (size_t)b * strideB;
+    cplx* C = Call + (size_t)b * strideC;
+    int tr0, tm, tc0, tn;
+    zf_block_range((M + 15) >> 4, nbm, blockIdx.y, &tr0, &tm);
+    zf_block_range((N + 15) >> 4, nbn, blockIdx.x, &tc0, &tn);
+    const int row0 = tr0 * 16, col0 = tc0 * 16, rows = tm * 16, cols = tn * 16, ntiles = tm * tn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fk = lane >> 4;
+
+    d4 accr[ZF_MAXT], acci[ZF_MAXT];
+    int toffA[ZF_MAXT], toffB[ZF_MAXT];          // LDS offsets of the sub-tile's A rows / B columns
+#pragma unroll
+    for (int s = 0; s < ZF_MAXT; ++s) {
+        accr[s] = (d4){0, 0, 0, 0}; acci[s] = (d4){0, 0, 0, 0};
+        const int t = wave + s * ZF_WAVES;
+        const int ti = t < ntiles ? t / tn : 0, tj = t < ntiles ? t - (t / tn) * tn : 0;
+        toffA[s] = (ti * 16 + fi) * ZF_APITCH + fk;
+        toffB[s] = fk * ZF_BPITCH + tj * 16 + fi;
+    }
+    // staging: A block rows x 16, B block 16 x cols; element e of a thread's share: index tid + e * 512
+    constexpr int NE = (ZF_ROWS * ZG_BK + ZF_THREADS - 1) / ZF_THREADS;          // 4 (3.5 rounded up)
+    cplx ra[NE], rb[NE];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * ZF_THREADS;
+            {   // A: row idx / 16, k idx % 16
+                const int r = idx >> 4, k = idx & 15, gi = row0 + r, gk = k0 + k;
+                ra[e] = (r < rows && gi < M && gk < K) ? A[(size_t)gi * lda + gk] : cmake(0.0, 0.0);
+            }
+            if (opB == 0) {   // B[k][j]: k = idx / cols16, j = idx % cols16 with cols16 = 112
+                const int k = idx / ZF_ROWS, j = idx - k * ZF_ROWS, gk = k0 + k, gj = col0 + j;
+                rb[e] = (k < ZG_BK && j < cols && gk < K && gj < N) ? B[(size_t)gk * ldb + gj] : cmake(0.0, 0.0);
+            } else {          // op(B)[k][j] = conj(B[j][k]); B stored N x K: j = idx / 16, k = idx % 16
+                const int j = idx >> 4, k = idx & 15, gj = col0 + j, gk = k0 + k;
+                rb[e] = (j < cols && gj < N && gk < K) ? cconj(B[(size_t)gj * ldb + gk]) : cmake(0.0, 0.0);
+            }
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += ZG_BK) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * ZF_THREADS;
+            if (idx < ZF_ROWS * ZG_BK) {
+                As[(idx >> 4) * ZF_APITCH + (idx & 15)] = ra[e];
+                if (opB == 0) { const int k = idx / ZF_ROWS, j = idx - k * ZF_ROWS; Bs[k * ZF_BPITCH + j] = rb[e]; }
+                else Bs[(idx & 15) * ZF_BPITCH + (idx >> 4)] = rb[e];
+            }
+        }
+        __syncthreads();
+        if (k0 + ZG_BK < K) fetch(k0 + ZG_BK);
+#pragma unroll
+        for (int ks = 0; ks < ZG_BK; ks += 4) {
+#pragma unroll
+            for (int s = 0; s < ZF_MAXT; ++s) {
+                if (wave + s * ZF_WAVES < ntiles) {              // wave-uniform
+                    const cplx af = As[toffA[s] + ks];
+                    const cplx bf = Bs[toffB[s] + ks * ZF_BPITCH];
+                    accr[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, bf.x, accr[s], 0, 0, 0);
+                    accr[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af.y, bf.y, accr[s], 0, 0, 0);
+                    acci[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, bf.y, acci[s], 0, 0, 0);
+                    acci[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, bf.x, acci[s], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < ZF_MAXT; ++s) {
+        const int t = wave + s * ZF_WAVES;
+        if (t < ntiles) {
+            const int ti = t / tn, tj = t - ti * tn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = row0 + ti * 16 + fk + 4 * r, gj = col0 + tj * 16 + fi;
+                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(accr[s][r], acci[s][r]);
+            }
+        }
+    }
+}
+
 // Plain VALU version (no matrix cores): kept as the independent cross-check of
 // the MFMA fragment maps (tests compare the two) and selectable with
 // NEGF_ZGEMM_ALGO=valu for debugging.
@@ -209,9 +318,23 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
         hipLaunchKernelGGL(zgemm_valu_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
                            strideB, opB, C, ldc, strideC);
     } else {
-        dim3 grid((N + ZG_BN - 1) / ZG_BN, (M + ZG_BM - 1) / ZG_BM, nb);
-        hipLaunchKernelGGL(zgemm_mfma_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
-                           strideB, opB, C, ldc, strideC);
+        // how much of the 64 x 64 blocks' area is padding beyond the 16-granular tiles?  Above 20 % the
+        // flexible-block kernel (balanced blocks of <= 7 x 7 sub-tiles) is used
+        const long tm16 = (M + 15) >> 4, tn16 = (N + 15) >> 4;
+        const long bm64 = (M + ZG_BM - 1) / ZG_BM, bn64 = (N + ZG_BN - 1) / ZG_BN;
+        static int flex_env = -1;
+        if (flex_env < 0) { const char* e = getenv("NEGF_ZGEMM_FLEX"); flex_env = e ? atoi(e) : 1; }
+        const bool padded = 10 * (bm64 * 4 * bn64 * 4) > 12 * (tm16 * tn16);
+        if (flex_env == 2 || (flex_env == 1 && padded)) {
+            const int nbm = (int)((tm16 + ZF_MAXT - 1) / ZF_MAXT), nbn = (int)((tn16 + ZF_MAXT - 1) / ZF_MAXT);
+            dim3 grid(nbn, nbm, nb);
+            hipLaunchKernelGGL(zgemm_flex_kernel, grid, dim3(ZF_THREADS), 0, st, M, N, K, nbm, nbn, A, lda, strideA,
+                               B, ldb, strideB, opB, C, ldc, strideC);
+        } else {
+            dim3 grid((unsigned)bn64, (unsigned)bm64, nb);
+            hipLaunchKernelGGL(zgemm_mfma_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
+                               strideB, opB, C, ldc, strideC);
+        }
     }
 }
 

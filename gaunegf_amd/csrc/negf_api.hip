@@ -128,9 +128,11 @@ int ensure_workspace(negf_ctx* c, int m, int blk_stride, int min_batch = 1)
         free_workspace(c);
         const size_t n2 = (size_t)c->n * c->n;
         int rc;
-        if ((rc = dev_alloc(&c->d_A, n2 * want))) return rc;
-        if ((rc = dev_alloc(&c->d_T1, n2 * want))) return rc;
-        if ((rc = dev_alloc(&c->d_T2, n2 * want))) return rc;
+        // (+ 64 elements of slack: the column-block update of the windowed inverse reads 64 consecutive
+        //  elements of a row from the window's first column whatever the window width; k_inverse_blocked.hip)
+        if ((rc = dev_alloc(&c->d_A, n2 * want + 64))) return rc;
+        if ((rc = dev_alloc(&c->d_T1, n2 * want + 64))) return rc;
+        if ((rc = dev_alloc(&c->d_T2, n2 * want + 64))) return rc;
         if ((rc = dev_alloc(&c->d_ipiv, (size_t)2 * c->n * want))) return rc;
         if ((rc = dev_alloc(&c->d_site, (size_t)c->n * want))) return rc;
         c->batch = want;

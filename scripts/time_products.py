@@ -1,25 +1,31 @@
-"""Time the dense product paths (GrLessInt, transmission) at a few sizes with the library's own
-hipEvent profile; prints per-family milliseconds."""
+"""Time the dense complex products (G Gamma G^H: two zgemm per energy) at a few sizes through GrLessInt with
+the dense-Gamma path forced; kernel time of the zgemm family from the library's hipEvents."""
 import sys, time, numpy as np
 sys.path.insert(0, '/root/repo')
+import torch
 from tests.helpers import random_system
 from gaunegf_amd.engine import get_engine
 from gaunegf_amd.matTools import formSigma
+sizes = [int(a) for a in sys.argv[1:]] or [192, 200, 208, 256, 500]
 eng = get_engine()
-for n, m in ((200, 1000), (500, 400), (1000, 128)):
-    F, S = random_system(n, 1)
-    nc = n // 10
-    sig = [formSigma(list(range(nc)), -0.1j, n, S), formSigma(list(range(n - nc, n)), -0.1j, n, S)]
+eng.set_gamma_algo(1)
+for n in sizes:
+    m = 1000 if n <= 512 else 256
+    F, S = random_system(n, seed=1)
+    sig = [formSigma(list(range(20)), -0.1j, n, S), formSigma(list(range(n - 20, n)), -0.1j, n, S)]
     eng.set_system(F, S)
     h = eng.sigma_const(sig)
-    E = np.linspace(-3, 3, m) + 0j; w = np.ones(m, dtype=complex) / m
-    eng.gless_int(h, -1, E, w); eng.transmission(h, 0, 1, E)
+    dev = torch.device("cuda", eng.device)
+    E = torch.complex(torch.linspace(-3, 3, m, dtype=torch.float64), torch.full((m,), 1e-3, dtype=torch.float64)).to(dev)
+    w = torch.full((m,), 1.0 / m, dtype=torch.complex128, device=dev)
+    out = torch.zeros((n, n), dtype=torch.complex128, device=dev)
+    for _ in range(2):
+        eng.gless_int_dev(h, -1, m, E.data_ptr(), w.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
     eng.profile(True); eng.profile_reset()
-    t0 = time.perf_counter(); eng.gless_int(h, -1, E, w); t1 = time.perf_counter(); eng.transmission(h, 0, 1, E); t2 = time.perf_counter()
-    fam = {f: eng.profile_read(f) for f in ("inverse", "zgemm", "gamma", "accumulate", "trace", "assemble")}
-    eng.profile(False)
-    zg_ms, zg_n = fam["zgemm"]
-    print(f"n={n} m={m}: gless {1e3*(t1-t0):.2f} ms, transmission {1e3*(t2-t1):.2f} ms; " +
-          ", ".join(f"{k} {v[0]:.2f} ms/{v[1]}" for k, v in fam.items()) +
-          f"; zgemm {4 * 8.0 * n**3 * m / (zg_ms * 1e-3) / 1e12:.1f} TF")
+    for _ in range(3):
+        eng.gless_int_dev(h, -1, m, E.data_ptr(), w.data_ptr(), out.data_ptr())
+    torch.cuda.synchronize()
+    zms, nl = eng.profile_read("zgemm"); ims, _ = eng.profile_read("inverse"); eng.profile(False)
+    print(f"n={n} m={m}: two products {zms/3:.2f} ms = {16*n**3*m/(zms/3*1e-3)/1e12:.1f} TF; inverse {ims/3:.2f} ms", flush=True)
     eng.sigma_free(h)
