@@ -236,7 +236,7 @@ def worker(args):
         launches_per_step = ch_launches / args.steps
         avg_chain_ms = ch_ms / ch_launches
         achieved = flops_chain_step / launches_per_step / (avg_chain_ms * 1e-3) / 1e12 if ch_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes("chain1d", "r02_pmc_c3_per_launch_avg.json")
+        traffic, traffic_src = pmc_traffic_bytes("chain1d_rs_kernel", "r02_pmc_c3_per_launch_avg.json")
         inv_tf = 8.0 * N ** 3 * M * args.steps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
         line = {
             "metric": "energy-points/sec (complex128 G(E) solves)",

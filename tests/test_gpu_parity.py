@@ -65,6 +65,24 @@ def test_G_of_E_per_energy(engine, N, algo):
         assert rel_fro(G[k], ref[k]) < TOL, (N, algo, k, rel_fro(G[k], ref[k]))
 
 
+@pytest.mark.parametrize("N,M", [(320, 11), (333, 8), (449, 17)])
+def test_windowed_inverse_batch_shapes(engine, N, M):
+    """The column-block update of the windowed inverse maps workgroups to (matrix, column block) through an
+    XCD-aware order padded to multiples of eight matrices: batches that are not multiples of eight, a dimension
+    that is a multiple of the 64-column window (320), a last window of 13 columns (333) and of one column (449)."""
+    from gaunegf_amd.integrate import GrBatch
+    F, S, g_dev, g_ref = _const_provider(N, 300 + N, nc=20)
+    E = np.linspace(-2.5, 2.5, M) + 0.02j
+    G = GrBatch(F, S, g_dev, E)
+    for k in (0, M // 2, M - 1):
+        ref = oracle.gr_batch(F, S, g_ref, E[k:k + 1])[0]
+        assert rel_fro(G[k], ref) < TOL, (N, M, k, rel_fro(G[k], ref))
+    # every matrix of the batch: residual against its own system
+    for k in range(M):
+        A = E[k] * S - F - np.asarray(g_ref.sigmaTot(E[k]))
+        assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9, (N, M, k)
+
+
 @pytest.mark.parametrize("N,M", [(12, 12), (60, 100), (200, 64)])
 def test_GrInt_GrLessInt_const_sigma(engine, N, M):
     from gaunegf_amd.integrate import GrInt, GrLessInt
