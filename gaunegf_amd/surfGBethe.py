@@ -227,7 +227,7 @@ class surfGBAt:
 
     def calcFermi(self, ne, fGuess=5, tol=FERMI_CALCULATION_TOL):
         """Contact Fermi level from the electron count (surfGBethe.py:1158-1188)."""
-        from .fermi import getFermiContact
+        from .density import getFermiContact
         self.fermi = getFermiContact(self, ne, tol, ENERGY_MIN, 1000, T=self.T, nOrbs=dim)
         return self.fermi
 
@@ -327,7 +327,7 @@ class surfGB:
         self.Vlists = [[construct_sk_matrix(self.Vdict, d) for d in dl] for dl in self.dirLists]
         self.gList = [surfGBAt(self.H0.copy(), Sl, Vl, eta, T) for Sl, Vl in zip(self.Slists, self.Vlists)]
         if fermi is None:
-            from .fermi import getFermiContact
+            from .density import getFermiContact
             fermi = getFermiContact(self.gList[0], self.ne / 2, FERMI_CALCULATION_TOL, ENERGY_MIN, 1000,
                                     T=T, nOrbs=dim)
         for g in self.gList:
