@@ -222,7 +222,8 @@ struct PanelSteps {
             }
             // (4) rank-1 update of every strip in sub-strips of 8 (bounded register use): a batch
             //     of LDS reads of the pivot row part, then register arithmetic
-            constexpr int HS = (S >= 8) ? 8 : S;
+            // (a pure-panel configuration with extra update waves runs 12 waves: 168 VGPRs, pivot row in chunks of 4)
+            constexpr int HS = (C::CPR == 1 && C::NW > C::PW) ? 4 : ((S >= 8) ? 8 : S);
 #pragma unroll
             for (int s0 = 0; s0 < S; s0 += HS) {
                 cplx rb[HS];
@@ -818,6 +819,162 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
     if (tid == 0 && bad_sh != 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad_sh;
 }
 
+// ---- Window kernel with LOOK-AHEAD inside the window (n <= 512: one row per panel-team lane).  The plain
+// window kernel alternates two phases that leave most of the CU idle in turn -- the pivot steps of a
+// sub-panel (a latency chain of LDS round trips and team barriers: 28 of the 75 us a sub-panel takes at
+// n = 500) and the in-window update (all waves streaming the n x 64 window block through the matrix cores
+// at Infinity-Cache bandwidth: 27-40 us).  Here twelve waves share them out:
+//   after sub-panel s is factored, ALL waves apply it to the 16 columns of sub-panel s+1 only (look-ahead),
+//   then waves 0-7 (the panel team) factor sub-panel s+1 WHILE waves 8-11 apply sub-panel s to the other
+//   columns of the window; the last sub-panel's update is shared by all twelve.
+// Transforms reach every column block in their order (each phase ends in a workgroup barrier); the panel
+// team only touches the columns of the sub-panel it factors, the update team everything else.
+constexpr int LA_PW = 8, LA_NW = 12, LA_THREADS = LA_NW * 64;
+
+template <int NBI>
+__global__ __launch_bounds__(LA_THREADS) void gj_window_la_kernel(
+    int n, cplx* __restrict__ bufA, size_t mat_stride,
+    int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw,
+    unsigned long long* __restrict__ stamps /* diagnostic (NEGF_GJ_STAMPS): workgroup 0, window 1; nullptr in production */)
+{
+    using C = GjCfg<NBI, 1, 1, LA_PW, LA_NW>;
+    constexpr int S = NBI, KS = NBI / 4, WT = WIN / 16, PTL = LA_PW * 64;
+    static_assert(NBI == 16, "sub-panel = one column tile");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cplx* cand = reinterpret_cast<cplx*>(smem_raw);              // [2][PW][NBI] candidate pivot rows
+    cplx* qwin = cand + 2 * LA_PW * NBI;                         // [NBI][WIN] pivot rows, window columns
+    __shared__ u64 slot[3];
+    __shared__ int bad_sh;
+    __shared__ int team_ctr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cplx* W = bufA + (size_t)blockIdx.x * mat_stride;
+    int* pivrow = piv_all + (size_t)blockIdx.x * 2 * n;
+    int* colof = pivrow + n;
+    int team_expect = 0;
+    if (tid == 0) { bad_sh = 0; team_ctr = 0; }
+    if (tid < 3) slot[tid] = 0;
+    __syncthreads();
+
+    const int fi = lane & 15, fk = lane >> 4;
+    const int tiles = (n + 15) >> 4;
+    const int nsub = (cw + NBI - 1) / NBI;                       // sub-panels = column tiles of the window
+
+    // apply sub-panel [k0, k0+kw) (its columns: the P operand, global; its pivot rows in the window columns:
+    // qwin, LDS) to the column tiles of the window selected by tmask; row tiles widx, widx + nw, ...
+    auto update_tiles = [&](int k0, int kw, unsigned tmask, int widx, int nw) __attribute__((always_inline)) {
+        for (int ti = widx; ti < tiles; ti += nw) {
+            const int prow = min(ti * 16 + fi, n - 1);
+            cplx pa[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pa[ks] = W[(size_t)prow * n + min(k0 + ks * 4 + fk, n - 1)];   // k >= kw pairs with Q == 0
+            bool keep[4];
+            const cplx* crow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = min(ti * 16 + fk + 4 * r, n - 1);
+                const int cf = colof[i];
+                keep[r] = !(cf >= k0 && cf < k0 + kw);
+                crow[r] = W + (size_t)i * n;
+            }
+            // the C tiles of every selected column tile are requested before the first MFMA: one L2 / Infinity-
+            // Cache round trip per row tile, not one per 16 x 16 tile
+            cplx cv[WT][4];
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                if ((tmask >> t) & 1u) {                             // (uniform)
+                    const int colc = min(c0 + t * 16 + fi, n - 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[t][r] = crow[r][colc];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < WT; ++t) {
+                if ((tmask >> t) & 1u) {                             // (uniform)
+                    const int col = c0 + t * 16 + fi;
+                    const bool col_store = col < n && col < c0 + cw;
+                    d4 accr, acci;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { accr[r] = keep[r] ? cv[t][r].x : 0.0; acci[r] = keep[r] ? cv[t][r].y : 0.0; }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const cplx qb = qwin[(ks * 4 + fk) * WIN + t * 16 + fi];
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.x, accr, 0, 0, 0);
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, -qb.y, accr, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.y, acci, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.x, acci, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = ti * 16 + fk + 4 * r;
+                        if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                    }
+                }
+            }
+        }
+    };
+    const unsigned all_tiles = (1u << nsub) - 1u;
+    int sti = 0;
+    auto stamp = [&](int w) __attribute__((always_inline)) {      // slot sti: wave w's clock at this point
+        if (stamps && blockIdx.x == 0 && wave == w && lane == 0 && sti < 60) stamps[sti] = __builtin_amdgcn_s_memrealtime();
+        ++sti;
+    };
+    stamp(0);
+
+    for (int sp = 0; sp < nsub; ++sp) {
+        const int k0 = c0 + sp * NBI, kw = min(NBI, c0 + cw - k0);
+        __syncthreads();                 // [A] look-ahead columns (global stores) complete
+        stamp(0);                        // 1 + 6 sp: [A] passed
+        if (wave < LA_PW) {
+            // ---- panel team: strips of the sub-panel in registers, pivot steps, strips back
+            cplx a[1][S];
+            bool avail[1];
+            const int r = tid;
+            const bool row_ok = r < n;
+            avail[0] = row_ok && (colof[row_ok ? r : 0] < 0);
+            {
+                const cplx* g = W + (size_t)(row_ok ? r : 0) * n + k0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) a[0][s] = (row_ok && s < kw) ? g[s] : cmake(0.0, 0.0);
+            }
+            PanelCtx<C> ctx{a, avail, cand, slot, &bad_sh, pivrow, colof,
+                            &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, nullptr};
+            publish_candidate<C>(ctx, 0, 0, 0);
+            team_sync<LA_PW>(&team_ctr, team_expect, lane);
+            PanelSteps<C, 0>::run(ctx);
+            if (row_ok) {
+                cplx* g = W + (size_t)r * n + k0;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    if (s < kw) g[s] = a[0][s];
+            }
+        } else if (sp > 0) {
+            // ---- update team: the previous sub-panel reaches the columns outside itself and this sub-panel
+            update_tiles(k0 - NBI, NBI, all_tiles & ~(3u << (sp - 1)), wave - LA_PW, LA_NW - LA_PW);
+        }
+        stamp(0);                        // panel team done (wave 0)
+        stamp(LA_PW);                    // update team done (wave 8)
+        __syncthreads();                 // [B] sub-panel columns, pivrow / colof (global) visible; Q of sp-1 free
+        stamp(0);                        // [B] passed
+        for (int t = tid; t < NBI * WIN; t += LA_THREADS) {
+            const int k = t / WIN, j = t - k * WIN;
+            qwin[t] = (k < kw && c0 + j < n && j < cw) ? W[(size_t)pivrow[k0 + k] * n + c0 + j] : cmake(0.0, 0.0);
+        }
+        __syncthreads();                 // [C]
+        stamp(0);                        // [C] passed: Q staged
+        if (sp + 1 < nsub) update_tiles(k0, kw, 1u << (sp + 1), wave, LA_NW);       // look-ahead, all waves
+        stamp(0);                        // look-ahead done (wave 0)
+    }
+    {
+        // the last sub-panel reaches all other columns of the window (all twelve waves)
+        const int sp = nsub - 1, k0 = c0 + sp * NBI, kw = min(NBI, c0 + cw - k0);
+        update_tiles(k0, kw, all_tiles & ~(1u << sp), wave, LA_NW);
+        stamp(0);                        // last update done (wave 0)
+    }
+    if (tid == 0 && bad_sh != 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad_sh;
+}
+
 // ---- Column-block big update.  One workgroup (512 threads, 8 waves, one per CU) OWNS a block of 64 columns
 // outside the window and applies the window to all of its rows:
 //     W[i][J] = (row i pivot of the window ? 0 : W[i][J]) + P'[i][0:cw) * Q[0:cw)[J]
@@ -1000,12 +1157,18 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         want_stamps = getenv("NEGF_GJ_STAMPS") ? 1 : 0;
         if (want_stamps) { (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 64 * sizeof(unsigned long long)); }
     }
+    static int winla = -1;
+    if (winla < 0) { const char* e = getenv("NEGF_GJ_WINLA"); winla = e ? atoi(e) : 1; }
     hipLaunchKernelGGL(gj_state_init_kernel, dim3(nb), dim3(256), 0, st, n, piv, info);
     const int nblk = (n + 63) / 64;
     for (int c0 = 0; c0 < n; c0 += WIN) {
         const int cw = min(WIN, n - c0);
-        hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, stride, piv, info, c0, cw,
-                           c0 == WIN ? d_stamps : (unsigned long long*)nullptr);
+        if (NBI == 16 && RPT == 1 && winla)
+            hipLaunchKernelGGL(gj_window_la_kernel<16>, dim3(nb), dim3(LA_THREADS), smem, st, n, A, stride, piv, info, c0, cw,
+                               c0 == WIN ? d_stamps : (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, stride, piv, info, c0, cw,
+                               c0 == WIN ? d_stamps : (unsigned long long*)nullptr);
         if (nblk > 1)
             hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((nb + 7) / 8) * (nblk - 1)), dim3(CU_THREADS), 0, st,
                                n, nb, A, stride, (const int*)piv, c0, cw);
@@ -1017,6 +1180,14 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         unsigned long long h[64];
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         auto us = [&](int i) { return (double)(h[i] - h[0]) / 100.0; };
+        if (NBI == 16 && RPT == 1 && winla) {
+            fprintf(stderr, "[gj window-la stamps] n=%d window 1, workgroup 0 (us):", n);
+            for (int sp = 0; sp < 4; ++sp)
+                fprintf(stderr, " | sub %d: A %.1f panel %.1f upd-team %.1f B %.1f C %.1f look-ahead %.1f", sp, us(1 + 6 * sp), us(2 + 6 * sp),
+                        us(3 + 6 * sp), us(4 + 6 * sp), us(5 + 6 * sp), us(6 + 6 * sp));
+            fprintf(stderr, " | last update %.1f\n", us(25));
+            return;
+        }
         fprintf(stderr, "[gj window stamps] n=%d window 1, workgroup 0 (us):", n);
         const int nsub = (WIN + NBI - 1) / NBI;
         for (int sp = 0; sp < nsub && 1 + 5 * sp + 4 < 60; ++sp)
