@@ -223,7 +223,7 @@ struct PanelSteps {
             // (4) rank-1 update of every strip in sub-strips of 8 (bounded register use): a batch
             //     of LDS reads of the pivot row part, then register arithmetic
             // (a pure-panel configuration with extra update waves runs 12 waves: 168 VGPRs, pivot row in chunks of 4)
-            constexpr int HS = (C::CPR == 1 && C::NW > C::PW) ? 4 : ((S >= 8) ? 8 : S);
+            constexpr int HS = (C::CPR == 1 && (C::NW > C::PW || C::RPT >= 2)) ? (S >= 4 ? 4 : S) : ((S >= 8) ? 8 : S);
 #pragma unroll
             for (int s0 = 0; s0 < S; s0 += HS) {
                 cplx rb[HS];
