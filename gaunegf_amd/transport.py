@@ -83,13 +83,48 @@ class SigmaCalculator:
         return 1j * (sigma - np.conj(sigma).T)
 
     # ---- engine lowering ---------------------------------------------------
+    def _const_handle(self, engine, what, spin, matrix_size):
+        """Device-side CONST provider of the static self-energies, created once and kept with this object
+        (creating and freeing it per call costs several device allocations and frees -- 20 ms on some hosts
+        against 7 ms of kernels for 1000 energies at N = 200).  ``what``: "LR" = the two contacts, "tot" =
+        their sum as a single contact (DOS).  The entry is keyed on the engine generation (a change of the
+        matrix dimension drops every provider in the library) and on a checksum of the arrays, which the
+        caller owns and may change between calls."""
+        import zlib
+        a1 = np.ascontiguousarray(self._static(self.sig1))
+        a2 = np.ascontiguousarray(self._static(self.sig2))
+        stamp = (a1.shape, a2.shape, zlib.crc32(a1.view(np.uint8).reshape(-1)), zlib.crc32(a2.view(np.uint8).reshape(-1)))
+        cache = self.__dict__.setdefault("_lowered", {})
+        key = (id(engine), getattr(engine, "generation", 0), what, spin if spin in ('u', 'ro', 'g') else 'r', matrix_size)
+        hit = cache.get(key)
+        if hit is not None and hit[2] == stamp:
+            return hit[1]
+        if hit is not None:
+            hit[0].sigma_free(hit[1])
+        for k in [k for k in cache if k[1] != key[1]]:          # older generations: handles already dropped by the library
+            cache.pop(k)
+        s1 = self._expand(a1, spin, matrix_size)
+        s2 = self._expand(a2, spin, matrix_size)
+        h = engine.sigma_const([s1, s2]) if what == "LR" else engine.sigma_const([np.asarray(s1) + np.asarray(s2)])
+        cache[key] = (engine, h, stamp)
+        return h
+
+    def _release(self):
+        for eng, h, _ in self.__dict__.get("_lowered", {}).values():
+            eng.sigma_free(h)               # (a handle the library already dropped is a no-op there)
+        self.__dict__.get("_lowered", {}).clear()
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
     def _lower(self, engine, energies, spin, matrix_size):
         """Provider handle serving Sigma_tot, Sigma_L (contact 0) and Sigma_R (contact -1)
         for ``energies``.  Returns (handle, temporary)."""
         if not self.energy_dependent:
-            s1 = self._expand(self._static(self.sig1), spin, matrix_size)
-            s2 = self._expand(self._static(self.sig2), spin, matrix_size)
-            return engine.sigma_const([s1, s2]), True
+            return self._const_handle(engine, "LR", spin, matrix_size), False
         g = self.sig1
         native = hasattr(g, "_negf_lower")
         sig_size = getattr(g, "F", np.zeros((matrix_size, matrix_size))).shape[0] if native else None
@@ -227,8 +262,7 @@ def _dos_batch(F, S, sigma_calc, energies, spin):
             getattr(sigma_calc.sig1, "F", F).shape[0] == size:
         h, temp = sigma_calc.sig1._negf_lower(eng), False
     elif not sigma_calc.energy_dependent:
-        tot = np.asarray(sigma_calc.get_sigma_total(0.0, spin, size))
-        h, temp = eng.sigma_const([tot]), True
+        h, temp = sigma_calc._const_handle(eng, "tot", spin, size), False
     else:
         tot = np.stack([np.asarray(sigma_calc.get_sigma_total(E, spin, size)) for E in energies])
         h, temp = eng.sigma_precomputed(tot), True
