@@ -1083,8 +1083,6 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
                 const bool z = pflag[min(ib * 64 + wr + a * 16 + fk + 4 * r, n - 1)] != 0;
                 cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].y;
             }
-        if (ib + 1 < nblk) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
-        if (ib > 0) store_block(ib - 1);
         const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
         cplx af[2][2];
 #pragma unroll
@@ -1092,6 +1090,15 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int cur = ks & 1;
+            if (ks == 2) {
+                // the requests for row block ib+1 and the stores of row block ib-1 (~250 instructions of address
+                // arithmetic, LDS-DMA set-up and predicated stores) are issued HERE, behind the first 16 MFMAs:
+                // a wave issues them in the shadow of its matrix instructions instead of in front of them
+                __builtin_amdgcn_sched_barrier(0);
+                if (ib + 1 < nblk) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
+                if (ib > 0) store_block(ib - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (ks + 1 < 16) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) af[cur ^ 1][a] = ab[a * 16 * CU_AP + (ks + 1) * 4];
