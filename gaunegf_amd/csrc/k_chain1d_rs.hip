@@ -57,6 +57,7 @@ struct ChainRsArgs {
     int gold_lds_off, gold_lds_slots; // the first slots of a lane's copy live in LDS at this element offset
     const int* order;                // launch slot -> job (energy * n_contacts + contact), longest jobs first; or null
     unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
+    int simd_roles;                  // 1: wave roles follow the SIMD a wave runs on (see rs_wave_role), 0: the wave number
 };
 
 // maximum of a 32-bit key over the wave (all lanes active), wave-uniform result: four DPP steps inside
@@ -333,9 +334,10 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
 // panel s to the remaining column tiles (one owner per column tile, no barrier), one barrier at the end.
 template <int T16, int P, int TR>
 __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, cplx* rowline, int tid,
+                                           int wave /* role number of this wave, see rs_wave_role */, bool fixed_fw,
                                            unsigned long long* st = nullptr)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     int sti = 0;
     auto stamp = [&]() __attribute__((always_inline)) { if (st && tid == 0) st[sti] = __builtin_amdgcn_s_memrealtime(); ++sti; };
     const int npanels = (n + RS_NB - 1) / RS_NB;
@@ -343,7 +345,8 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
         const bool has_cur = sgi >= 0, has_next = sgi + 1 < npanels;
         const int p0 = has_cur ? sgi * RS_NB : 0, pw = has_cur ? min(RS_NB, n - p0) : 0;
         const int n0 = (sgi + 1) * RS_NB, nw = has_next ? min(RS_NB, n - n0) : 0;
-        const int fw = (sgi + 1) & (RS_WAVES - 1);              // the wave that factors panel sgi+1
+        // the wave that factors panel sgi+1: the chain wave (role RS_WAVES-1), or -- roles by wave number -- each in turn
+        const int fw = fixed_fw ? RS_WAVES - 1 : (sgi + 1) & (RS_WAVES - 1);
         if (has_cur && has_next) {
             // the look-ahead column tile, one row tile per wave (T16 <= 4 = number of waves)
             const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
@@ -414,7 +417,32 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     const int n = a.nc[c];
     const int off = a.blk_off[c];
     cplx* Ws = reinterpret_cast<cplx*>(smem_raw);       // [16*T16][P] (+ slack): g (start of a sweep), T, M, the reduced M
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // ---- wave roles.  A v_mfma_f64_16x16x4 holds its SIMD's vector issue for ~45 of its 64 cycles whatever the
+    // priorities (scripts/probe/fp64_coexec_probe.hip: beside a wave that streams them, another wave's v_fma_f64 take
+    // 22 cycles instead of 5.6 and an LDS round trip 230 instead of 105), so the wave that factors the panels -- a
+    // chain of dependent vector and LDS instructions, the workgroup's critical path -- must not share its SIMD with
+    // waves that stream matrix instructions.  The four waves of a workgroup always land on four different SIMDs
+    // (scripts/probe/wave_placement_probe.hip), so the roles follow the SIMD: the wave on SIMD 0 is the CHAIN wave
+    // (role 3: factors every panel; its share of the products and updates is the last tile, for n_c = 50 the
+    // 2-row / 2-column remainder strip), the waves on SIMDs 1-3 are the MATRIX waves (roles 0-2).  With several
+    // workgroups per CU all chain waves then sit on SIMD 0 and all matrix-instruction streams on SIMDs 1-3.
+    // Only speed depends on the placement: were two waves ever to report the same SIMD, the roles fall back to
+    // the wave numbers.
+    int wave = tid >> 6;
+    bool chain_roles = false;
+    if (a.simd_roles) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const int simd = (hwid >> 4) & 3;
+        if (lane == 0) flags[wave] = simd;
+        __syncthreads();
+        const int seen = (1 << flags[0]) | (1 << flags[1]) | (1 << flags[2]) | (1 << flags[3]);
+        chain_roles = __builtin_amdgcn_readfirstlane(seen) == 15;
+        if (chain_roles) wave = simd == 0 ? RS_WAVES - 1 : simd - 1;
+        wave = __builtin_amdgcn_readfirstlane(wave);
+        __syncthreads();
+    }
     const int fi = lane & 15, fk = lane >> 4;
     const int ksteps = (n + 3) >> 2;
     // the old iterate, element (ks*4 + fk, wave*16 + fi) of g at slot ks of this lane
@@ -626,7 +654,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     while (true) {
         unsigned long long* st = (a.stamps && job == 0 && count == 10) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-        rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
+        rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
         if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
         gather_mix(first);
         if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
@@ -770,6 +798,9 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     a.stamps = d_stamps;
     static int occ_env = -1;
     if (occ_env < 0) { const char* e = getenv("NEGF_CHAIN1D_OCC"); occ_env = e ? atoi(e) : 0; }
+    static int roles_env = -1;
+    if (roles_env < 0) { const char* e = getenv("NEGF_CHAIN1D_ROLES"); roles_env = e ? atoi(e) : 1; }
+    a.simd_roles = roles_env;
     // one instantiation per pitch class of the largest contact (smaller contacts of the same launch run
     // in the same padded matrix): the smallest odd pitch of the list that holds n_max columns
     const int n = p.nc_max;
