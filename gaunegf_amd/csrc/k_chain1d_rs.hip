@@ -108,8 +108,32 @@ __device__ __forceinline__ void zmfma4_conjb(double& ar, double& ai, cplx pa, cp
     ai = __builtin_amdgcn_mfma_f64_4x4x4f64(pa.y, b.x, ai, 0, 0, 0);
     ai = __builtin_amdgcn_mfma_f64_4x4x4f64(-pa.x, b.y, ai, 0, 0, 0);
 }
+#define RS_M3S(A, B, C, PR, PI, PS, QR, QI, QS) do { double a_ = (A)[0], b_ = (B)[0], c_ = (C)[0]; mfma3s(a_, b_, c_, PR, PI, PS, QR, QI, QS); (A)[0] = a_; (B)[0] = b_; (C)[0] = c_; } while (0)
 #define RS_ZMFMA4(ACCR, ACCI, PA, QB) do { double r_ = (ACCR)[0], i_ = (ACCI)[0]; zmfma4(r_, i_, PA, QB); (ACCR)[0] = r_; (ACCI)[0] = i_; } while (0)
 #define RS_ZMFMA4C(ACCR, ACCI, PA, QB) do { double r_ = (ACCR)[0], i_ = (ACCI)[0]; zmfma4_conjb(r_, i_, PA, QB); (ACCR)[0] = r_; (ACCI)[0] = i_; } while (0)
+
+// ---- complex products by three real ones ("3M"): with p = pr + i pi, q = qr + i qi
+//        a = sum pr qr,   b = sum pi qi,   c = sum (pr + pi)(qr + qi)     =>  p q       = (a - b) + i (c - a - b)
+//        a, b as above,                    c = sum (pr + pi)(qr - qi)     =>  p conj(q) = (a + b) + i (c - a + b)
+// i.e. 3 matrix instructions per tile and k-step instead of 4: a quarter of the matrix-pipe time of every product
+// and update, for one or two additions per operand fragment.  The FP64 matrix instruction holds its SIMD's vector
+// issue for most of its 64 cycles (rs_wave_role below), so matrix-pipe time is what the sweep is made of.
+__device__ __forceinline__ void mfma3(d4& a, d4& b, d4& c, double pr, double pi, double ps, double qr, double qi, double qs)
+{
+    a = __builtin_amdgcn_mfma_f64_16x16x4f64(pr, qr, a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, qi, b, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(ps, qs, c, 0, 0, 0);
+}
+#ifndef RS_3M_GEMM
+#define RS_3M_GEMM 1
+#endif
+// the same on the 4x4x4 instruction (remainder strips, one value per lane)
+__device__ __forceinline__ void mfma3s(double& a, double& b, double& c, double pr, double pi, double ps, double qr, double qi, double qs)
+{
+    a = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, qr, a, 0, 0, 0);
+    b = __builtin_amdgcn_mfma_f64_4x4x4f64(pi, qi, b, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f64_4x4x4f64(ps, qs, c, 0, 0, 0);
+}
 
 // Hide a loop-invariant value from the optimiser: without this LLVM hoists every (tile, k-step)
 // LDS address of the sweep out of the fixed-point loop -- hundreds of live address registers that
@@ -210,7 +234,7 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
 // ---- trailing update with panel [p0, p0+pw), in place:
 //        W[i][col] = (i pivot row of the panel ? 0 : W[i][col]) + P[i][:] Q[:][col]
 // A Q fragment holds the panel's pivot rows in the columns of one column tile (B operand); for the
-// column-strip tile TR every 4-column block holds the same columns TR*16 + (l&3) (see zmfma4).
+// column-strip tile TR every 4-column block holds the same columns TR*16 + (l&3) (see mfma3s).
 template <int P, int NKS, int TR /* last tile when it is a remainder strip, else -1 */>
 __device__ __forceinline__ void rs_load_qf(const cplx* W, const int* pivrow, int tj, int p0, int pw, int fi, int fk,
                                            cplx (&qf)[NKS])
@@ -240,18 +264,22 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
         for (int r = 0; r < 4; ++r) { cf[r] = colof[ti * 16 + fk + 4 * r]; cv[r] = cbase[4 * r * P]; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) pa[ks] = pbase[ks * 4];
-        d4 accr, acci;
+        constexpr bool M3 = P > 35;                         // 3M (mfma3) in the 168-VGPR kernels
+        d4 ua, ub = {0, 0, 0, 0}, uc;                       // accumulators, seeded with the old tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool keep = !(cf[r] >= p0 && cf[r] < p0 + pw);
-            accr[r] = keep ? cv[r].x : 0.0; acci[r] = keep ? cv[r].y : 0.0;
+            ua[r] = keep ? cv[r].x : 0.0; uc[r] = keep ? (M3 ? cv[r].x + cv[r].y : cv[r].y) : 0.0;
         }
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) zmfma(accr, acci, pa[ks], qf[ks]);
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (M3) mfma3(ua, ub, uc, pa[ks].x, pa[ks].y, pa[ks].x + pa[ks].y, qf[ks].x, qf[ks].y, qf[ks].x + qf[ks].y);
+            else zmfma(ua, uc, pa[ks], qf[ks]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + fk + 4 * r;
-            if (i < n && tj * 16 + fi < n) cbase[4 * r * P] = cmake(accr[r], acci[r]);
+            if (i < n && tj * 16 + fi < n) cbase[4 * r * P] = M3 ? cmake(ua[r] - ub[r], uc[r] - ua[r] - ub[r]) : cmake(ua[r], uc[r]);
         }
     } else {
         const int row = rowstrip ? TR * 16 + fk : ti * 16 + 4 * (fi >> 2) + fk;
@@ -265,10 +293,11 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) pa[ks] = prow[ks * 4];
         const bool keep = !(cf >= p0 && cf < p0 + pw);
-        double ar = keep ? cv.x : 0.0, ai = keep ? cv.y : 0.0;
+        double ua = keep ? cv.x : 0.0, ub = 0.0, uc = keep ? cv.x + cv.y : 0.0;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) zmfma4(ar, ai, pa[ks], qf[ks]);
-        if (mine && row < n && col < n) *cptr = cmake(ar, ai);
+        for (int ks = 0; ks < NKS; ++ks)
+            mfma3s(ua, ub, uc, pa[ks].x, pa[ks].y, pa[ks].x + pa[ks].y, qf[ks].x, qf[ks].y, qf[ks].x + qf[ks].y);
+        if (mine && row < n && col < n) *cptr = cmake(ua - ub, uc - ua - ub);
     }
 }
 
@@ -291,6 +320,10 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
         return;
     }
     const int col = tj * 16 + fi;
+    constexpr bool M3 = P > 35;                              // 3M (mfma3) in the 168-VGPR kernels
+    double qs[NKS];                                          // 3M: re + im of the Q fragment, once per column tile
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qs[ks] = qf[ks].x + qf[ks].y;
     cplx* cbase = W + fk * P + col;                          // C tile element (ti*16 + fk + 4r, col)
     const cplx* pbase = W + fi * P + p0 + fk;                // P operand element (ti*16 + fi, p0 + ks*4 + fk)
     const int* cfb = colof + fk;
@@ -309,18 +342,22 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
     for (int ti = 0; ti < FT; ++ti) {
         const int s = ti & 1;
         if (ti + 1 < FT) fetch(ti + 1, s ^ 1);
-        d4 accr, acci;
+        d4 ua, ub = {0, 0, 0, 0}, uc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool keep = !(cf[s][r] >= p0 && cf[s][r] < p0 + pw);
-            accr[r] = keep ? cv[s][r].x : 0.0; acci[r] = keep ? cv[s][r].y : 0.0;
+            ua[r] = keep ? cv[s][r].x : 0.0; uc[r] = keep ? (M3 ? cv[s][r].x + cv[s][r].y : cv[s][r].y) : 0.0;
         }
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) zmfma(accr, acci, pa[s][ks], qf[ks]);
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (M3) mfma3(ua, ub, uc, pa[s][ks].x, pa[s][ks].y, pa[s][ks].x + pa[s][ks].y, qf[ks].x, qf[ks].y, qs[ks]);
+            else zmfma(ua, uc, pa[s][ks], qf[ks]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + fk + 4 * r;
-            if (i < n && col < n) cbase[(ti * 16 + 4 * r) * P] = cmake(accr[r], acci[r]);
+            // with a remainder strip (TR >= 0) the full tiles lie inside the matrix: rows, columns < 16 TR < n
+            if (TR >= 0 || (i < n && col < n)) cbase[(ti * 16 + 4 * r) * P] = M3 ? cmake(ua[r] - ub[r], uc[r] - ua[r] - ub[r]) : cmake(ua[r], uc[r]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -403,6 +440,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     constexpr int TR = T16 - 1;                         // the last tile
     constexpr bool REM = RS_REMAINDER && T16 >= 2 && P - 16 * TR <= 4;   // ... holds <= 4 rows / columns: strips
     constexpr int FT = REM ? TR : T16;                  // full 16 x 16 tiles per dimension
+    constexpr bool M3G = T16 >= 3;                      // products in 3M form (mfma3): the 168-VGPR kernels
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ int flags[2 * RS_WAVES];                 // per wave: any(diff > conv), all(diff <= conv)
     __shared__ int pivrow[64], colof[64];
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
 
     // wave w: acc[tj] = sum_k Op[w*16 + fi][k] * Ws[k][tj*16 + fi]  (row tile w of  Op Ws).  The padding of
     // Ws is zero / finite, output columns >= n are never stored.
-    auto gemm_rowtile = [&](d4 (&accr)[T16], d4 (&acci)[T16]) __attribute__((always_inline)) {
+    auto gemm_rowtile = [&](d4 (&accr)[T16], d4 (&acci)[T16], d4 (&accc)[T16]) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
         const bool strip_wave = REM && wave == TR;      // this wave's row tile is the row strip
         const cplx* bb = Ws + fk * P + fi;
@@ -498,11 +536,12 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
 #pragma unroll
         for (int ks = 0; ks < PF; ++ks) stream_fetch(q, sS, sM, ks, fk);
 #pragma unroll
-        for (int tj = 0; tj < T16; ++tj) { accr[tj] = (d4){0, 0, 0, 0}; acci[tj] = (d4){0, 0, 0, 0}; }
+        for (int tj = 0; tj < T16; ++tj) { accr[tj] = (d4){0, 0, 0, 0}; acci[tj] = (d4){0, 0, 0, 0}; accc[tj] = (d4){0, 0, 0, 0}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
                 const cplx pa = stream_elem(q, ks, fk);
+                const double ps = pa.x + pa.y;
                 if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
                 cplx qb[T16];
 #pragma unroll
@@ -510,11 +549,11 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                 if (REM) qb[TR] = strip_wave ? bb[ks * 4 * P + TR * 16] : bb4[ks * 4 * P + TR * 16];
                 if (strip_wave) {
 #pragma unroll
-                    for (int tj = 0; tj < T16; ++tj) RS_ZMFMA4(accr[tj], acci[tj], pa, qb[tj]);
+                    for (int tj = 0; tj < T16; ++tj) { if (M3G) RS_M3S(accr[tj], acci[tj], accc[tj], pa.x, pa.y, ps, qb[tj].x, qb[tj].y, qb[tj].x + qb[tj].y); else RS_ZMFMA4(accr[tj], acci[tj], pa, qb[tj]); }
                 } else {
 #pragma unroll
-                    for (int tj = 0; tj < FT; ++tj) zmfma(accr[tj], acci[tj], pa, qb[tj]);
-                    if (REM) RS_ZMFMA4(accr[TR], acci[TR], pa, qb[TR]);
+                    for (int tj = 0; tj < FT; ++tj) { if (M3G) mfma3(accr[tj], acci[tj], accc[tj], pa.x, pa.y, ps, qb[tj].x, qb[tj].y, qb[tj].x + qb[tj].y); else zmfma(accr[tj], acci[tj], pa, qb[tj]); }
+                    if (REM) { if (M3G) RS_M3S(accr[TR], acci[TR], accc[TR], pa.x, pa.y, ps, qb[TR].x, qb[TR].y, qb[TR].x + qb[TR].y); else RS_ZMFMA4(accr[TR], acci[TR], pa, qb[TR]); }
                 }
             }
             // the LDS operands of the next k-step are not requested earlier than this: the register file
@@ -524,7 +563,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         }
     };
     // wave w: acc[ti] = sum_k Ws[ti*16 + fi][k] * conj(Op[w*16 + fi][k])  (column tile w of  Ws Op^H)
-    auto gemm_coltile = [&](d4 (&accr)[T16], d4 (&acci)[T16]) __attribute__((always_inline)) {
+    auto gemm_coltile = [&](d4 (&accr)[T16], d4 (&acci)[T16], d4 (&accc)[T16]) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
         const bool strip_wave = REM && wave == TR;      // this wave's column tile is the column strip
         const cplx* ab = Ws + fi * P + fk;
@@ -535,11 +574,12 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
 #pragma unroll
         for (int ks = 0; ks < PF; ++ks) stream_fetch(q, sS, sM, ks, fk);
 #pragma unroll
-        for (int ti = 0; ti < T16; ++ti) { accr[ti] = (d4){0, 0, 0, 0}; acci[ti] = (d4){0, 0, 0, 0}; }
+        for (int ti = 0; ti < T16; ++ti) { accr[ti] = (d4){0, 0, 0, 0}; acci[ti] = (d4){0, 0, 0, 0}; accc[ti] = (d4){0, 0, 0, 0}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
                 const cplx br = stream_elem(q, ks, fk);
+                const double bd = br.x - br.y;
                 if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
                 cplx pa[T16];
 #pragma unroll
@@ -548,16 +588,19 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                 // pa * conj(b)
                 if (strip_wave) {
 #pragma unroll
-                    for (int ti = 0; ti < T16; ++ti) RS_ZMFMA4C(accr[ti], acci[ti], pa[ti], br);
+                    for (int ti = 0; ti < T16; ++ti) { if (M3G) RS_M3S(accr[ti], acci[ti], accc[ti], pa[ti].x, pa[ti].y, pa[ti].x + pa[ti].y, br.x, br.y, bd); else RS_ZMFMA4C(accr[ti], acci[ti], pa[ti], br); }
                 } else {
 #pragma unroll
                     for (int ti = 0; ti < FT; ++ti) {
-                        accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].x, br.x, accr[ti], 0, 0, 0);
-                        accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.y, accr[ti], 0, 0, 0);
-                        acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.x, acci[ti], 0, 0, 0);
-                        acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ti].x, br.y, acci[ti], 0, 0, 0);
+                        if (M3G) mfma3(accr[ti], acci[ti], accc[ti], pa[ti].x, pa[ti].y, pa[ti].x + pa[ti].y, br.x, br.y, bd);
+                        else {
+                            accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].x, br.x, accr[ti], 0, 0, 0);
+                            accr[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.y, accr[ti], 0, 0, 0);
+                            acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ti].y, br.x, acci[ti], 0, 0, 0);
+                            acci[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[ti].x, br.y, acci[ti], 0, 0, 0);
+                        }
                     }
-                    if (REM) RS_ZMFMA4C(accr[TR], acci[TR], pa[TR], br);
+                    if (REM) { if (M3G) RS_M3S(accr[TR], acci[TR], accc[TR], pa[TR].x, pa[TR].y, pa[TR].x + pa[TR].y, br.x, br.y, bd); else RS_ZMFMA4C(accr[TR], acci[TR], pa[TR], br); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -567,7 +610,13 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // (rows ti*16 + fk + 4r, column tj*16 + fi; a row strip only fills r = 0), a COLUMN-STRIP tile (tj == TR of a
     // full row tile) holds one value per lane at (ti*16 + 4 (fi>>2) + fk, TR*16 + (fi&3)).
     // f(i, j, re, im) is called for every element this lane holds.
-    auto for_tile = [&](int ti, int tj, const d4& vr, const d4& vi, int fi, int fk, auto f) __attribute__((always_inline)) {
+    auto for_tile = [&](int ti, int tj, const d4& va, const d4& vb, const d4& vc, bool cj, int fi, int fk, auto f) __attribute__((always_inline)) {
+        d4 vr, vi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            vr[r] = !M3G ? va[r] : cj ? va[r] + vb[r] : va[r] - vb[r];
+            vi[r] = !M3G ? vb[r] : cj ? vc[r] - va[r] + vb[r] : vc[r] - va[r] - vb[r];
+        }
         if (REM && tj == TR && ti != TR) {
             f(ti * 16 + 4 * (fi >> 2) + fk, TR * 16 + (fi & 3), vr[0], vi[0]);
         } else {
@@ -577,11 +626,11 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         }
     };
     // store row tile `wave` held as accumulators (C layout: rows fk + 4r, column fi of tile tj)
-    auto store_rowtile = [&](const d4 (&accr)[T16], const d4 (&acci)[T16]) __attribute__((always_inline)) {
+    auto store_rowtile = [&](const d4 (&accr)[T16], const d4 (&acci)[T16], const d4 (&accc)[T16]) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
 #pragma unroll
         for (int tj = 0; tj < T16; ++tj)
-            for_tile(wave, tj, accr[tj], acci[tj], fi, fk,
+            for_tile(wave, tj, accr[tj], acci[tj], accc[tj], false, fi, fk,
                      [&](int i, int j, double re, double im) { if (i < n && j < n) Ws[i * P + j] = cmake(re, im); });
     };
     // g_new[k][col] = W[pivrow[k]][colof[col]] for this lane's elements; first: g = g_new, else the
@@ -664,21 +713,21 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
             final_pass = true;
             opS = Stau; opM = tau; opz = e;
         }
-        d4 mr[T16], mi[T16];
+        d4 mr[T16], mi[T16], mc[T16];
         // T = B g : row tile `wave`; g is read from Ws by every wave, so T waits in registers
-        gemm_rowtile(mr, mi);
+        gemm_rowtile(mr, mi, mc);
         __syncthreads();
-        store_rowtile(mr, mi);
+        store_rowtile(mr, mi, mc);
         __syncthreads();
         if (st && tid == 0) st[3] = __builtin_amdgcn_s_memrealtime();
         // T B^H : column tile `wave`
-        gemm_coltile(mr, mi);
+        gemm_coltile(mr, mi, mc);
         const int fis = rs_opaque(lane & 15), fks = rs_opaque(lane >> 4);
         if (final_pass) {
             cplx* out = blk + (size_t)b * a.blk_stride + off;
 #pragma unroll
             for (int ti = 0; ti < T16; ++ti)
-                for_tile(ti, wave, mr[ti], mi[ti], fis, fks,
+                for_tile(ti, wave, mr[ti], mi[ti], mc[ti], true, fis, fks,
                          [&](int i, int j, double re, double im) { if (i < n && j < n) out[i * n + j] = cmake(re, im); });
             break;
         }
@@ -686,7 +735,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         // M = A - T B^H
 #pragma unroll
         for (int ti = 0; ti < T16; ++ti) {
-            for_tile(ti, wave, mr[ti], mi[ti], fis, fks, [&](int i, int j, double re, double im) {
+            for_tile(ti, wave, mr[ti], mi[ti], mc[ti], true, fis, fks, [&](int i, int j, double re, double im) {
                 const cplx av = Aat(i, j);
                 if (i < n && j < n) Ws[i * P + j] = cmake(av.x - re, av.y - im);
             });

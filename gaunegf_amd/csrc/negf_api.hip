@@ -79,7 +79,7 @@ void free_provider(SigmaProvider* p)
     dev_free(p->d_inds); dev_free(p->d_nc); dev_free(p->d_blk_off); dev_free(p->d_inds_off);
     dev_free(p->d_n_atoms); dev_free(p->d_atom_off);
     dev_free(p->d_alpha); dev_free(p->d_Salpha); dev_free(p->d_beta); dev_free(p->d_Sbeta);
-    dev_free(p->d_tau); dev_free(p->d_Stau);
+    dev_free(p->d_tau); dev_free(p->d_Stau); dev_free(p->d_lead_pad);
     dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
     dev_free(p->d_H); dev_free(p->d_Slist); dev_free(p->d_Vlist); dev_free(p->d_xi);
     dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order);
@@ -652,6 +652,20 @@ int negf_sigma_chain1d(negf_ctx* c, int n_contacts, const int* nc, const int* in
     for (int k = 0; k < 6; ++k) {
         if ((rc = dev_alloc(dsts[k], tot)) ||
             (rc = upload(c, *dsts[k], reinterpret_cast<const cplx*>(srcs[k]), tot))) { free_provider(p); return rc; }
+    }
+    if (chain1d_lds_supported(p->nc_max)) {
+        constexpr int LP = 64;
+        std::vector<cplx> pad((size_t)n_contacts * 6 * LP * LP, cmake(0.0, 0.0));
+        for (int k = 0; k < n_contacts; ++k)
+            for (int m = 0; m < 6; ++m) {
+                const cplx* src = reinterpret_cast<const cplx*>(srcs[m]) + p->blk_off[k];
+                cplx* dst = pad.data() + ((size_t)k * 6 + m) * LP * LP;
+                for (int i = 0; i < nc[k]; ++i)
+                    for (int j = 0; j < nc[k]; ++j) dst[i * LP + j] = src[i * nc[k] + j];
+            }
+        if ((rc = dev_alloc(&p->d_lead_pad, pad.size())) || (rc = upload(c, p->d_lead_pad, pad.data(), pad.size()))) {
+            free_provider(p); return rc;
+        }
     }
     p->eta = eta; p->conv = conv; p->relFactor = relFactor; p->max_iter = max_iter;
     p->force_iters = force_iters;

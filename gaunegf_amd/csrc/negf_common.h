@@ -84,6 +84,9 @@ struct SigmaProvider {
     // CHAIN1D matrices, concatenated [sum nc^2] each
     cplx *d_alpha = nullptr, *d_Salpha = nullptr, *d_beta = nullptr, *d_Sbeta = nullptr,
          *d_tau = nullptr, *d_Stau = nullptr;
+    // the same six matrices per contact, zero-padded to 64 x 64 ([contact][6][64][64]; nc_max <= 64 only):
+    // operand streams of chain1d_rs_kernel, which then needs no index clamps
+    cplx* d_lead_pad = nullptr;
     double eta = 0, conv = 0, relFactor = 0, mix = 0;
     int max_iter = 0, force_iters = -1;
     // job order learned from the previous evaluation of a grid of order_n jobs (chain kernel)
