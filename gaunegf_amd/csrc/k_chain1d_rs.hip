@@ -60,25 +60,27 @@ struct ChainRsArgs {
     int simd_roles;                  // 1: wave roles follow the SIMD a wave runs on (see rs_wave_role), 0: the wave number
 };
 
-// maximum of a 32-bit key over the wave (all lanes active), wave-uniform result: four DPP steps inside
-// the rows of 16 lanes (v_max_u32 with a DPP source), then the four row results through v_readlane
-template <int CTRL>
+// maximum of a 32-bit key over the wave (all lanes active), wave-uniform result.  Four DPP steps inside the rows
+// of 16 lanes leave the row maximum in every lane of a row; row_bcast:15 / row_bcast:31 (the GFX9 wave-reduction
+// steps) then carry it across the rows into lane 63: seven vector instructions and one v_readlane.  With
+// bound_ctrl and a zero "old" value the compiler folds each lane move into its v_max_u32 (v_max_u32_dpp);
+// zero is the identity of the maximum, and the row steps read no invalid lane.
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ unsigned rs_dpp_max_u32(unsigned k)
 {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, 0xF, 0xF, false);
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, ROW_MASK, 0xF, true);
     return o > k ? o : k;
 }
 
 __device__ __forceinline__ unsigned rs_wave_max_u32(unsigned k)
 {
-    k = rs_dpp_max_u32<0xB1>(k);      // quad_perm [1,0,3,2]
-    k = rs_dpp_max_u32<0x4E>(k);      // quad_perm [2,3,0,1]
-    k = rs_dpp_max_u32<0x141>(k);     // row_half_mirror
-    k = rs_dpp_max_u32<0x140>(k);     // row_mirror
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)k, 0), b = (unsigned)__builtin_amdgcn_readlane((int)k, 16);
-    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)k, 32), d = (unsigned)__builtin_amdgcn_readlane((int)k, 48);
-    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
+    k = rs_dpp_max_u32<0xB1>(k);            // quad_perm [1,0,3,2]
+    k = rs_dpp_max_u32<0x4E>(k);            // quad_perm [2,3,0,1]
+    k = rs_dpp_max_u32<0x141>(k);           // row_half_mirror
+    k = rs_dpp_max_u32<0x140>(k);           // row_mirror: every lane of a row holds the row maximum
+    k = rs_dpp_max_u32<0x142, 0xA>(k);      // row_bcast:15 into rows 1 and 3
+    k = rs_dpp_max_u32<0x143, 0xC>(k);      // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
 }
 
 // ---- remainder tiles.  n_c = 50 is three tiles of 16 and two more rows / columns; a fourth 16 x 16 tile for
@@ -492,6 +494,9 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // off, the scratch of the workgroups of an XCD fits its 4 MB L2 and is rewritten there sweep after sweep.
     cplx* gold_g = GOLD_GLOBAL ? a.gold + ((size_t)slot * KS) * RS_THREADS + tid : nullptr;
     cplx* gold_l = Ws + a.gold_lds_off + fk * n + wave * 16 + fi;
+    // LDS slots of the old iterate: LS_CT (what fits when n = P, a compile-time number) or one more
+    constexpr int LS_FIT = (16 * T16 * P + 16 - (P + 2) * P) / (4 * P);
+    constexpr int LS_CT = GOLD_GLOBAL ? (LS_FIT > 0 ? LS_FIT : 0) : KS;
     const int lds_slots = GOLD_GLOBAL ? a.gold_lds_slots : KS;
 
     const cplx* alpha = a.alpha + off; const cplx* Salpha = a.Salpha + off;
@@ -636,49 +641,66 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // g_new[k][col] = W[pivrow[k]][colof[col]] for this lane's elements; first: g = g_new, else the
     // reference's mixing and stopping test (surfG1D.py:276-284).  Leaves g in Ws and in gold.
     int over = 1, allok = 0;
-    auto gather_mix = [&](bool first) __attribute__((always_inline)) {
+    auto gather_mix = [&](bool first, unsigned long long* st) __attribute__((always_inline)) {
         const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
         const int col = wave * 16 + fi;
-        const cplx* gsrc = Ws + colof[min(col, n - 1)];
+        const bool colok = col < n;
+        const int colc = min(col, n - 1);               // every load below is unconditional, at a clamped (valid) address
         const int* pvr = pivrow + fk;
         cplx* gdst = Ws + fk * P + col;
-        cplx* gl = rs_opaque(gold_l);
+        cplx* gl = rs_opaque(gold_l) - col + colc;
         cplx* gg = GOLD_GLOBAL ? rs_opaque(gold_g) : nullptr;
-        bool lane_over = false, lane_ok = true;
-        cplx gm[KS];
+        // slot ks of the old iterate lives in LDS?  compile-time below / above LS_CT, wave-uniform at LS_CT
+        auto in_lds = [&](int ks) { return !GOLD_GLOBAL || ks < LS_CT || (ks == LS_CT && lds_slots > LS_CT); };
+        // element (ks*4 + fk, col) exists?  with a remainder strip all k-steps below 4 TR hold rows < 16 TR < n
+        auto valid = [&](int ks) { return colok && ((REM && ks * 4 + 3 < 16 * TR) || ks * 4 + fk < n); };
+        // All requests of the phase go out in three batches -- pivot indices, old iterate (global scratch: the
+        // longest latency, requested before the gathers), gathered new iterate -- instead of slot by slot: the
+        // phase is three dependent round trips long, not thirteen.
+        int pr[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = ks * 4 + fk;
-            gm[ks] = cmake(0.0, 0.0);
-            if (ks < ksteps && k < n && col < n) {
-                const cplx gn = gsrc[pvr[ks * 4] * P];
-                if (first) {
-                    gm[ks] = gn;
-                } else {
-                    const cplx go = (!GOLD_GLOBAL || ks < lds_slots) ? gl[ks * 4 * n] : gg[ks * RS_THREADS];
-                    const double dx = gn.x - go.x, dy = gn.y - go.y;
+        for (int ks = 0; ks < KS; ++ks) pr[ks] = ks < ksteps ? pvr[ks * 4] : 0;
+        const cplx* gsrc = Ws + colof[colc];
+        cplx go[KS], gm[KS];
+        if (!first) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                if (ks < ksteps) go[ks] = in_lds(ks) ? gl[ks * 4 * n] : gg[ks * RS_THREADS];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) gm[ks] = ks < ksteps ? gsrc[pr[ks] * P] : cmake(0.0, 0.0);
+        if (st && tid == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st[5] = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[6] = __builtin_amdgcn_s_memrealtime(); }
+        bool lane_over = false, lane_ok = true;
+        if (!first) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < ksteps) {
+                    const cplx gn = gm[ks];
+                    const double dx = gn.x - go[ks].x, dy = gn.y - go[ks].y;
                     const double num2 = dx * dx + dy * dy;
                     const double den2 = fmax(gn.x * gn.x + gn.y * gn.y, 1e-24);
-                    lane_over |= num2 > conv2 * den2;
-                    lane_ok &= num2 <= conv2 * den2;
-                    gm[ks] = cmake(gn.x * rf + go.x * rf1, gn.y * rf + go.y * rf1);
+                    const bool v = valid(ks);
+                    lane_over |= v && num2 > conv2 * den2;
+                    lane_ok &= !v || num2 <= conv2 * den2;
+                    gm[ks] = cmake(gn.x * rf + go[ks].x * rf1, gn.y * rf + go[ks].y * rf1);
                 }
-                if (!GOLD_GLOBAL || ks < lds_slots) gl[ks * 4 * n] = gm[ks]; else gg[ks * RS_THREADS] = gm[ks];
             }
-            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // four gathers in flight, not sixteen
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            if (ks < ksteps && valid(ks)) { if (in_lds(ks)) gl[ks * 4 * n] = gm[ks]; else gg[ks * RS_THREADS] = gm[ks]; }
         if (!first) {
             const bool w_over = __ballot(lane_over) != 0ull;
             const bool w_ok = __ballot(!lane_ok) == 0ull;
             if (lane == 0) { flags[wave] = w_over ? 1 : 0; flags[RS_WAVES + wave] = w_ok ? 1 : 0; }
         }
+        if (st && tid == 0) st[7] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();                                // all gathers done: Ws may be overwritten
+        if (st && tid == 0) st[40] = __builtin_amdgcn_s_memrealtime();
         if (tid < 64) colof[tid] = -1;                  // for the next inverse (every lane has read its colof)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = ks * 4 + fk;
-            if (ks < ksteps && k < n && col < n) gdst[ks * 4 * P] = gm[ks];
-        }
+        for (int ks = 0; ks < KS; ++ks)
+            if (ks < ksteps && valid(ks)) gdst[ks * 4 * P] = gm[ks];
         if (!first) {
             over = flags[0] | flags[1] | flags[2] | flags[3];
             allok = flags[4] & flags[5] & flags[6] & flags[7];
@@ -705,7 +727,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
         rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
         if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
-        gather_mix(first);
+        gather_mix(first, st);
         if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
         if (!first) ++count;
         first = false;
@@ -811,7 +833,9 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
     ChainRsArgs al = a; al.gold_lds_off = 16 * T16 * P + 16; al.gold_lds_slots = 1 << 20;
     // ... or its first slots in the unused rows n_max+2 .. of the work matrix, the rest in global scratch
     ChainRsArgs ag = a; ag.gold_lds_off = (n_max + 2) * P;
-    ag.gold_lds_slots = std::max(0, (16 * T16 * P + 16 - ag.gold_lds_off) / (4 * n_max));
+    constexpr int LS_FIT = (16 * T16 * P + 16 - (P + 2) * P) / (4 * P);      // the kernel's LS_CT
+    ag.gold_lds_slots = std::min(std::max(0, (16 * T16 * P + 16 - ag.gold_lds_off) / (4 * n_max)), std::max(LS_FIT, 0) + 1);
+    if (ag.gold_lds_slots < std::max(LS_FIT, 0)) ag.gold_lds_slots = 0;       // (cannot happen: n_max <= P)
     auto launch = [&](auto kern, size_t smem) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             (void)hipGetLastError();
@@ -878,6 +902,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
             fprintf(stderr, "[chain stamps] sweep 10 (us): inverse %.2f  diff+mix %.2f  T=Bg %.2f  M=A-TB^H %.2f  (total %.2f) | inverse stages:",
                     us(1), us(2) - us(1), us(3) - us(2), us(4) - us(3), us(4));
             for (int i = 8; i < 16 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) / 100.0);
+            fprintf(stderr, " | mix: lds %.2f vmem %.2f computed+stored %.2f barrier %.2f", us(5) - us(1), us(6) - us(1), us(7) - us(1), us(40) - us(1));
             fprintf(stderr, " | factor begin-end:");
             for (int i = 24; i < 34 && h[i]; i += 2) fprintf(stderr, " %.2f-%.2f", (double)(h[i] - h[0]) / 100.0, (double)(h[i + 1] - h[0]) / 100.0);
             fprintf(stderr, "\n");
