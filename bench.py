@@ -20,6 +20,15 @@ relaxation 0.1, at most 2000 sweeps), form Sigma = t g t^H, assemble E S - F - S
 the N_orb x N_orb result.  F, S, the lead matrices, the energy grid and the weights are resident in
 HBM before the timed region; the result stays in HBM.
 
+--config c4 / c5 run BASELINE's multi-GPU configurations through the drop-in Python API with the product's own
+energy sharding (gaunegf_amd.distributed: cyclic shard, ONE sum all-reduce per integral, ONE all-gather of the
+per-energy scalars), STRONG scaling (the grid is fixed, the ranks divide it):
+  c4: N_orb = 800, Bethe-lattice Sigma (Au.bethe, 2 contacts x 3 atoms x 9 orbitals); one step = GrInt over the
+      486-point ANT contour + GrInt over the 256-point real-axis grid (the density-matrix build of SURVEY 8d C4);
+  c5: 2 x 1000 spin-block F / S, qV = 0.5 V window at 300 K, 512 Legendre points; one step = GrLessInt(ind=-1)
+      + calculate_transmission(spin='u') on that grid.
+The default (c3) is the headline and the only configuration with CPU / secondary legs.
+
 The JSON line carries
   roofline     : the kernel that dominates the step (the chain fixed point, > 90 % of it) against the
                  FP64 matrix-core peak.  achieved = algorithmic flops per launch / average launch
@@ -95,12 +104,12 @@ def _blas_limits():
 
 
 def cpu_baseline(make_call, n_total, label, budget_s, probe_pts=2):
-    """Time `make_call(idx)` (an oracle integral over the energies idx) on a bounded sample.
+    """Time `make_call(idx)` (an oracle integral over the energies idx) on a bounded sample, in THIS process.
 
     The BLAS thread count that is fastest for this workload on this host is used (all cores is not
     the fastest for these matrix sizes: oversubscription); `cores` reports that thread count."""
     limits = _blas_limits()
-    ncpu = os.cpu_count() or 1
+    ncpu = host_cpus()
     cands = sorted({t for t in (1, 4, 16, ncpu) if t <= ncpu}) if limits else [ncpu]
     probe_idx = np.linspace(0, n_total - 1, probe_pts).astype(int)
     best_t, best_per, by_threads = ncpu, None, {}
@@ -126,26 +135,100 @@ def cpu_baseline(make_call, n_total, label, budget_s, probe_pts=2):
             "points_per_s_by_blas_threads": by_threads,
             "sample": f"{n} of {n_total} energies (evenly spaced, {100.0 * n / n_total:.1f} % of the grid) of {label}; "
                       f"numpy {np.__version__} oracle loop (reference CPU restatement), best of BLAS threads {cands} "
-                      f"= {best_t} (host has {ncpu} logical CPUs), {dt:.1f} s"}
+                      f"= {best_t} (host has {ncpu} usable CPUs), {dt:.1f} s"}
 
 
-def pmc_traffic_bytes(kernel_substr, fname):
-    """HBM bytes per launch from a committed PMC profile (separate --pmc passes): 2 x FETCH_SIZE
-    (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE,
-    both in KiB."""
-    path = os.path.join(ROOT, "profiles", fname)
+def host_cpus():
+    """CPUs this process may use (affinity / container share), not the machine's total."""
     try:
-        data = json.load(open(path))
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+# ---- whole-host baseline: a pool of oracle processes over the energies, one BLAS thread each -- the reference's own
+# answer to "a Python loop over 50 x 50 matrices cannot use BLAS threads" (gauNEGF/density.py:121-210, chunked Pool).
+_POOL = {}
+
+
+def _pool_init(kind, payload):
+    import oracle
+    limits = _blas_limits()
+    if limits:
+        _POOL["limits"] = limits(limits=1)
+    if kind == "c3":
+        F, S, inds, kw, eta = payload
+        _POOL["F"], _POOL["S"] = F, S
+        _POOL["g"] = oracle.Chain1DSigma(F, S, inds, kw["taus"], kw["staus"], kw["alphas"], kw["aOverlaps"],
+                                         kw["betas"], kw["bOverlaps"], eta=eta)
+    else:
+        F, S, inds, gamma = payload
+        _POOL["F"], _POOL["S"] = F, S
+        _POOL["g"] = oracle.ConstSigma(F, S, inds, gamma)
+
+
+def _pool_chunk(args):
+    import oracle
+    E, w = args
+    return oracle.GrInt(_POOL["F"], _POOL["S"], _POOL["g"], E, w)
+
+
+def cpu_baseline_pool(kind, payload, E, w, n_sample, label, workers=None):
+    """`n_sample` evenly spaced energies of the grid, dealt to `workers` processes (default: the usable CPUs, at
+    most NEGF_BENCH_CPU_WORKERS = 16 -- the CPU share of a one-GPU box); wall time from the first task to the
+    last result, the pool's start-up (process spawn, imports) excluded."""
+    import multiprocessing as mp
+    workers = workers or max(1, min(host_cpus(), int(os.environ.get("NEGF_BENCH_CPU_WORKERS", "16"))))
+    idx = np.linspace(0, E.size - 1, min(n_sample, E.size)).astype(int)
+    chunks = [(E[c], w[c]) for c in np.array_split(idx, min(len(idx), workers * 4)) if len(c)]
+    ctx = mp.get_context("spawn")                        # never fork a process that has initialised the GPU
+    with ctx.Pool(workers, initializer=_pool_init, initargs=(kind, payload)) as pool:
+        pool.map(_pool_chunk, chunks[:workers])          # warm-up: imports, first BLAS calls
+        t0 = time.perf_counter()
+        parts = pool.map(_pool_chunk, chunks, chunksize=1)
+        dt = time.perf_counter() - t0
+    assert np.all(np.isfinite(sum(parts)))
+    return {"value": len(idx) / dt, "unit": "energy-points/s", "cores": int(workers), "kind": "port",
+            "sample": f"{len(idx)} of {E.size} energies (evenly spaced, {100.0 * len(idx) / E.size:.1f} % of the grid) of "
+                      f"{label}; numpy {np.__version__} oracle loop (reference CPU restatement) in {workers} processes "
+                      f"x 1 BLAS thread ({host_cpus()} usable CPUs of {os.cpu_count()} on the host), {dt:.1f} s"}
+
+
+def kernel_source_id(fname="k_chain1d_rs.hip"):
+    """sha256 (16 hex digits) of a kernel source file: what a profile must have been taken on to be quoted."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "gaunegf_amd", "csrc", fname), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def pmc_traffic_bytes(kernel_substr, source_file="k_chain1d_rs.hip"):
+    """HBM bytes per launch from a committed PMC profile (separate --pmc passes): 2 x FETCH_SIZE (gfx950 reports
+    half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.
+    Only a profile whose kernel name matches AND that records the sha256 of the kernel source it was taken on
+    (key "_kernel_source_sha16", written by scripts/pmc_summarize.py) equal to the tree's is quoted; otherwise
+    (None, reason): a stale number is worse than none."""
+    want = kernel_source_id(source_file)
+    reason = "no PMC profile of this kernel under profiles/"
+    for fname in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (fname.endswith(".json") and "pmc" in fname):
+            continue
+        try:
+            data = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        except Exception:
+            continue
         for name, ctr in data.items():
-            if kernel_substr in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.join("profiles", fname)
-    except Exception:
-        pass
-    return None, None
+            if isinstance(ctr, dict) and kernel_substr in name and "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                if data.get("_kernel_source_sha16", {}).get(source_file) == want and want is not None:
+                    return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.join("profiles", fname)
+                reason = f"profiles/{fname} was taken on another version of {source_file}"
+    return None, reason
 
 
 # ---------------------------------------------------------------------------------- the worker
-def worker(args):
+def _init_ranks():
+    """(torch, dist, world, rank, local_rank, rehearsal) with the process group initialised for world > 1."""
     import torch
     import torch.distributed as dist
 
@@ -159,6 +242,7 @@ def worker(args):
     rehearsal = os.environ.get("NEGF_BENCH_REHEARSAL", "0") == "1"
     if rehearsal:
         local_rank = local_rank % torch.cuda.device_count()
+        os.environ["LOCAL_RANK"] = str(local_rank)      # get_engine() picks the device from it
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -166,6 +250,11 @@ def worker(args):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return torch, dist, world, rank, local_rank, rehearsal
+
+
+def worker_c3(args):
+    torch, dist, world, rank, local_rank, rehearsal = _init_ranks()
 
     from gaunegf_amd.engine import Engine
     from gaunegf_amd.surfG1D import surfG
@@ -236,7 +325,7 @@ def worker(args):
         launches_per_step = ch_launches / args.steps
         avg_chain_ms = ch_ms / ch_launches
         achieved = flops_chain_step / launches_per_step / (avg_chain_ms * 1e-3) / 1e12 if ch_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes("chain1d_rs_kernel", "r02_pmc_c3_per_launch_avg.json")
+        traffic, traffic_src = pmc_traffic_bytes("chain1d_rs_kernel")
         inv_tf = 8.0 * N ** 3 * M * args.steps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
         line = {
             "metric": "energy-points/sec (complex128 G(E) solves)",
@@ -279,10 +368,15 @@ def worker(args):
             ref = oracle.Chain1DSigma(F, S, inds, kw["taus"], kw["staus"], kw["alphas"], kw["aOverlaps"],
                                       kw["betas"], kw["bOverlaps"], eta=ETA)
             Er, wr = np.real(E_loc), np.real(w_loc)
-            line["cpu_baseline"] = cpu_baseline(lambda idx: oracle.GrInt(F, S, ref, Er[idx], wr[idx]), M,
-                                                f"the same C3 workload (N_orb={N}, n_c={NC} decimation, GrInt)",
-                                                budget_s=args.cpu_budget)
-            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            label = f"the same C3 workload (N_orb={N}, n_c={NC} decimation, GrInt)"
+            one = cpu_baseline(lambda idx: oracle.GrInt(F, S, ref, Er[idx], wr[idx]), M, label,
+                               budget_s=min(args.cpu_budget, 8.0))
+            # the whole-host figure: >= 5 % of the grid over a pool of single-thread oracle processes
+            pool = cpu_baseline_pool("c3", (F, S, inds, kw, ETA), Er, wr, max(M // 20, 64), label)
+            line["cpu_baseline"] = pool
+            line["cpu_baseline"]["one_process"] = {k: one[k] for k in ("value", "cores", "points_per_s_by_blas_threads", "sample")}
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / pool["value"]
+            line["cpu_baseline"]["gpu_over_one_process"] = line["value"] / one["value"]
         if not args.no_extra and world == 1:
             line["extra"] = {"north_star_N500_x_1000": extra_const(eng, 500, 50, 1000, 3, reps=3, cpu_budget=6.0,
                                                                    no_cpu=args.no_cpu),
@@ -291,6 +385,121 @@ def worker(args):
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+
+
+def _bethe_contacts(N):
+    """Geometry of C4's contacts: 2 contacts x 3 Au atoms x 9 orbitals at the two ends of an N-orbital
+    device; the remaining orbitals belong to one device 'atom'."""
+    coords = np.array([[0, 0, 0.0], [2.88, 0, 0], [1.44, 2.494, 0],
+                       [0, 0, 20.0], [2.88, 0, 20.0], [1.44, 2.494, 20.0], [1.44, 0.8, 10.0]])
+    orbMap = np.concatenate([np.full(9, a + 1) for a in range(6)] + [np.full(N - 54, 7)])
+    typ_one = np.array([0, 1001, 1002, 1003, 2001, 2002, 2003, 2004, 2005])
+    orbTyp = np.concatenate([typ_one] * 6 + [np.zeros(N - 54, dtype=int)])
+    return coords, orbMap, orbTyp
+
+
+def worker_api(args):
+    """BASELINE configs C4 / C5 through the drop-in API with the product's own energy sharding (strong scaling)."""
+    torch, dist, world, rank, local_rank, rehearsal = _init_ranks()
+    from gaunegf_amd import distributed as D
+    from gaunegf_amd import density as DN
+    from gaunegf_amd.engine import get_engine
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    if world > 1:
+        D.enable()
+    eng = get_engine()
+    if args.config == "c4":
+        from gaunegf_amd.surfGBethe import surfGB
+        N = 800
+        F, S = random_system(N, 4)
+        coords, orbMap, orbTyp = _bethe_contacts(N)
+        lat = os.path.join(ROOT, "tests", "golden", "Au")
+        g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
+        Ec, wc = DN.contour_grid(-8.0, 0.0, 486, 0.0)
+        Er, wr = DN.real_axis_grid(-1e6, -8.0, 256, 0.0)
+        pts_per_step, n_solve, solves_per_step, products_per_step = 742, N, 742, 0
+        workload = ("C4: N_orb=800, Bethe-lattice Sigma (Au.bethe, 2 contacts x 3 atoms x 9 orbitals, eta=1e-6); one step = "
+                    "GrInt over the 486-point ANT contour + GrInt over the 256-point real-axis grid, the grid sharded "
+                    f"cyclically over {world} GPU(s), one sum all-reduce per integral")
+
+        def step():
+            return GrInt(F, S, g, Ec, wc), GrInt(F, S, g, Er, wr)
+    else:
+        from gaunegf_amd.matTools import formSigma
+        from gaunegf_amd.surfGTester import surfGTest
+        from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+        N = 1000
+        Fa, Sa = random_system(N, 5); Fb, _ = random_system(N, 6)
+        Z = np.zeros((N, N))
+        F = np.block([[Fa, Z], [Z, Fb]]); S = np.kron(np.eye(2), Sa)
+        nc = 30
+        left = list(range(nc)); right = list(range(N - nc, N))
+        s1 = formSigma(left, -0.1j, N, Sa); s2 = formSigma(right, -0.1j, N, Sa)
+        g = surfGTest(F, S, [left + [N + i for i in left], right + [N + i for i in right]], -0.1j)
+        sc = SigmaCalculator(s1, s2)
+        M = 512
+        Eg, wg = DN.bias_window_grid(-0.25, 0.25, M, 300.0)
+        Et = np.real(np.asarray(Eg)).copy()
+        # two N = 1000 solves per energy and entry point (block-diagonal spin system), two dense products each
+        pts_per_step, n_solve, solves_per_step, products_per_step = 2 * M, N, 4 * M, 8 * M
+        workload = ("C5: 2 x 1000 spin-block F/S (scf.py:177-180 layout), qV=0.5 V window at 300 K, 512 Legendre points; one "
+                    "step = GrLessInt(ind=-1) + calculate_transmission(spin='u') on that grid (each as two N=1000 solves per "
+                    f"energy), the grid sharded cyclically over {world} GPU(s), one sum all-reduce / one all-gather each")
+
+        def step():
+            return GrLessInt(F, S, g, Eg, wg, -1), calculate_transmission(F, S, sc, Et, spin='u')
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):                # the first call uploads F / S and builds the providers
+        res = step()
+    fence()
+    eng.profile(True); eng.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    fams = ("inverse", "zgemm", "bethe", "assemble", "accumulate", "gamma", "trace")
+    prof = {k: eng.profile_read(k) for k in fams}
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert all(np.all(np.isfinite(np.asarray(r if not isinstance(r, tuple) else r[0]))) for r in res)
+    if rank == 0:
+        share = 1.0 / world                               # this rank's part of the grid
+        inv_ms = prof["inverse"][0]; gm_ms = prof["zgemm"][0]
+        inv_tf = 8.0 * n_solve ** 3 * solves_per_step * share * args.steps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
+        gm_tf = 8.0 * n_solve ** 3 * products_per_step * share * args.steps / (gm_ms * 1e-3) / 1e12 if gm_ms > 0 else 0.0
+        dom, dom_tf, dom_ms = ("zgemm_mfma_kernel (dense complex products G Gamma G^H, Gamma_L G Gamma_R G^H)", gm_tf, gm_ms) \
+            if gm_ms > inv_ms else ("windowed Gauss-Jordan inverse (gj_window* + gj_colupdate + gj_gather kernels)", inv_tf, inv_ms)
+        line = {
+            "metric": "energy-points/sec (complex128 G(E) solves)",
+            "value": args.steps * pts_per_step / dt, "unit": "energy-points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 (complex128)",
+            "data": "synthetic",
+            "config": {"workload": workload, "n_orb": N if args.config == "c4" else 2 * N,
+                       "energy_points_per_step": pts_per_step, "sharding": f"energy-cyclic x{world}",
+                       "density_matrix_wall_ms": dt / args.steps * 1e3},
+            "roofline": {"bound": "mfma", "achieved": dom_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": dom + " on rank 0's shard; 8 n^3 flop per solve / product",
+                         "family_ms_per_step": {k: prof[k][0] / args.steps for k in fams},
+                         "inverse_tflops": inv_tf, "zgemm_tflops": gm_tf,
+                         "share_of_step": dom_ms / args.steps / (dt / args.steps * 1e3)},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        D.disable()
         dist.destroy_process_group()
 
 
@@ -346,7 +555,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--energies", type=int, default=2000, help="energy points per GPU")
+    ap.add_argument("--config", choices=("c3", "c4", "c5"), default="c3",
+                    help="BASELINE configuration: c3 = the headline (weak scaling); c4, c5 = the multi-GPU configurations (strong scaling)")
+    ap.add_argument("--energies", type=int, default=2000, help="energy points per GPU (c3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the N_orb=500 x 1000 and C2 secondary lines")
     ap.add_argument("--cpu-budget", type=float, default=18.0, help="seconds of CPU work for the headline baseline")
@@ -362,7 +573,7 @@ def main():
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    worker(args)
+    (worker_c3 if args.config == "c3" else worker_api)(args)
 
 
 if __name__ == "__main__":

@@ -301,7 +301,10 @@ __global__ __launch_bounds__(BE_THREADS) void bethe_kernel(
             const int atom = a.atom_off[c] + ai;
             for (int q = a.nb_off[atom]; q < a.nb_off[atom + 1]; ++q) {
                 int nb = a.nb_dirs[q];
-                nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);      // JAX gather clamps out-of-range indices
+                // jax indexing of a length-9 array: a negative index wraps (numpy rule), what is still out of
+                // range clamps (jax retrieval rule); pinned against the reference's numpy twin inside 0..8 only
+                if (nb < 0) nb += 9;
+                nb = nb < 0 ? 0 : (nb > 8 ? 8 : nb);
                 v = csub(v, sig[nb * D2 + r]);
             }
         }

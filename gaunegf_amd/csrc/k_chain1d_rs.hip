@@ -781,7 +781,7 @@ __global__ __launch_bounds__(1024) void chain1d_order_kernel(const int* __restri
     int np2 = 1;
     while (np2 < count) np2 <<= 1;
     for (int t = threadIdx.x; t < np2; t += blockDim.x)
-        keys[t] = t < count ? iters[t] * RS_ORDER_MAX + (RS_ORDER_MAX - 1 - t) : -1;
+        keys[t] = t < count ? min(iters[t], 131071) * RS_ORDER_MAX + (RS_ORDER_MAX - 1 - t) : -1;    // 17 + 14 bits: no overflow for any max_iter
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {

@@ -100,14 +100,15 @@ void free_mbuffers(negf_ctx* c)
     c->m_cap = 0; c->contacts_cap = 0;
 }
 
-// Energies in flight for a grid of m points.  The workspace is sized for TWICE the grid (the transmission
-// entry point carves two work areas per energy out of it) so that the calls of one workflow -- GrInt, then
-// calculate_transmission, then GrLessInt on the same grid -- find it in place: it only ever grows, and only
-// when a larger grid arrives.
+// Energies in flight for a grid of m points.  Once the transmission entry point has been used on this context
+// the workspace is sized for TWICE the grid (it carves two work areas per energy out of it), so that the calls of
+// one workflow -- GrInt, calculate_transmission, GrLessInt on the same grid -- find it in place: it only ever
+// grows, and only when a larger grid arrives.  Contexts that only integrate (SCF loops, the headline bench) get
+// the single-grid size: half the HBM, which matters when ranks or processes share a device.
 int auto_batch(negf_ctx* c, int m)
 {
     if (c->batch_user > 0) return std::min(c->batch_user, std::max(m, 1));
-    m = 2 * std::max(m, 1);
+    m = (c->transmission_seen ? 2 : 1) * std::max(m, 1);
     // three n x n complex128 work matrices per in-flight energy.  The working set may take a
     // quarter of the free HBM (288 GB per MI355X), at most 64 GB: large matrices need hundreds of
     // energies in flight so that the one-workgroup-per-matrix panel kernels cover the 256 CUs
@@ -128,8 +129,8 @@ int ensure_workspace(negf_ctx* c, int m, int blk_stride, int min_batch = 1)
         free_workspace(c);
         const size_t n2 = (size_t)c->n * c->n;
         int rc;
-        // (+ 64 elements of slack: the column-block update of the windowed inverse reads 64 consecutive
-        //  elements of a row from the window's first column whatever the window width; k_inverse_blocked.hip)
+        // (+ 64 elements: a guard behind the last matrix; no kernel relies on it any more -- the column-block
+        //  update of the windowed inverse clamps its lane offset to the window width)
         if ((rc = dev_alloc(&c->d_A, n2 * want + 64))) return rc;
         if ((rc = dev_alloc(&c->d_T1, n2 * want + 64))) return rc;
         if ((rc = dev_alloc(&c->d_T2, n2 * want + 64))) return rc;
@@ -859,6 +860,7 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
     if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
     // two extra n x n work areas per energy for Gamma_L / Gamma_R: reuse T1/T2 for
     // the Gammas and carve the product temporaries out of a second workspace half
+    c->transmission_seen = true;
     if ((rc = ensure_workspace(c, m, p->blk_stride, 2))) return rc;
     const cplx* E = reinterpret_cast<const cplx*>(E_dev);
     // process with half the allocated batch so that [0,half) holds this sweep's

@@ -124,6 +124,7 @@ struct negf_ctx {
     cplx* d_S = nullptr;
     int batch_user = 0;            // 0 = auto
     int batch = 0;                 // allocated workspace batch
+    bool transmission_seen = false; // negf_transmission[_dev] has run on this context: size the workspace for it
     // workspace, sized for `batch` energies
     cplx* d_A = nullptr;           // [batch][n*n]   assembled matrix -> inverse in place
     cplx* d_T1 = nullptr;          // [batch][n*n]   temp products

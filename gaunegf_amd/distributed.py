@@ -104,11 +104,13 @@ def sharded_device_sum(engine, run_dev, E, w):
     out = torch.zeros((engine.n, engine.n), dtype=torch.complex128, device=dev)
     if idx.size:
         E_t, w_t = to_dev(E[idx]), to_dev(w[idx])
+        # the zero fill and the uploads ran on torch's stream, the engine accumulates on its own: order them
+        torch.cuda.current_stream(dev).synchronize()
         run_dev(int(idx.size), E_t.data_ptr(), w_t.data_ptr(), out.data_ptr())
     # (an empty shard -- fewer points than ranks -- still takes part in the collective, with zeros)
     engine.sync()                                   # the engine's stream -> visible to the collective's stream
     if idx.size:
-        engine.warn_if_singular_dev(int(idx.size), "sharded integral")
+        engine.warn_if_singular_dev(int(idx.size), "sharded integral", grid_index=idx)
     flat = torch.view_as_real(out)
     if dist.get_backend(_state["group"]) == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_state["group"])
@@ -128,14 +130,45 @@ def sharded_sum(partial_fn, m):
     return allreduce_sum(part)
 
 
+def all_gather_shards(part, m, device=None):
+    """Per-energy values of this rank's cyclic shard, ``part`` [len(shard), *tail] (float64 numpy), from every
+    rank -> the full [m, *tail] array on every rank.  ONE all-gather of ceil(m / W) rows per rank (SURVEY 8e:
+    "all-gather of M/8 doubles") instead of a sum over zero-filled length-m vectors; with the nccl backend the
+    shard is gathered on the device (RCCL over xGMI) and downloaded once, with a CPU backend (gloo: tests,
+    rehearsals on one GPU) on the host."""
+    import torch
+    dist = _dist()
+    rank, world = rank_world()
+    part = np.ascontiguousarray(part, dtype=np.float64)
+    tail = part.shape[1:]
+    cap = (m + world - 1) // world                      # rows of the largest shard
+    mine = torch.zeros((cap,) + tuple(tail), dtype=torch.float64)
+    if part.shape[0]:
+        mine[:part.shape[0]] = torch.from_numpy(part)
+    if dist.get_backend(_state["group"]) == "nccl":
+        mine = mine.cuda(device) if device is not None else mine.cuda()
+    if mine.is_cuda:
+        gathered = torch.empty((world, cap) + tuple(tail), dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(gathered, mine, group=_state["group"])
+    else:
+        chunks = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(chunks, mine, group=_state["group"])
+        gathered = torch.stack(chunks)
+    g = gathered.cpu().numpy()
+    full = np.empty((m,) + tuple(tail), dtype=np.float64)
+    for r in range(world):
+        idx = shard_indices(m, r, world)
+        full[idx] = g[r, :idx.size]
+    return full
+
+
 def sharded_map(partial_fn, m, tail_shape=()):
     """``partial_fn(idx)`` returns per-energy values [len(idx), *tail_shape]; returns
-    the full [m, *tail_shape] array on every rank."""
+    the full [m, *tail_shape] array on every rank (one all-gather of the shards)."""
     if not is_active():
         return partial_fn(slice(None))
     rank, world = rank_world()
     idx = shard_indices(m, rank, world)
-    full = np.zeros((m,) + tuple(tail_shape), dtype=np.float64)
-    if idx.size:
-        full[idx] = partial_fn(idx)
-    return allreduce_sum(full)
+    part = np.asarray(partial_fn(idx), dtype=np.float64).reshape((idx.size,) + tuple(tail_shape)) if idx.size \
+        else np.zeros((0,) + tuple(tail_shape))
+    return all_gather_shards(part, m)

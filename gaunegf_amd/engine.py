@@ -210,10 +210,12 @@ class Engine:
         assert E.size == w.size, "Elist and weights must have the same length"
         return E, w
 
-    def _numerical(self, rc, info, where):
+    def _numerical(self, rc, info, where, grid_index=None):
         self.last_info = info
         if rc == _lib.NEGF_ESINGULAR:
             bad = np.nonzero(info)[0]
+            if grid_index is not None:                  # positions in a shard -> indices of the caller's grid
+                bad = np.asarray(grid_index)[bad]
             warnings.warn(f"{where}: exactly singular E*S-F-Sigma at energy indices {bad[:8].tolist()}"
                           f"{'...' if bad.size > 8 else ''}", RuntimeWarning)
 
@@ -297,10 +299,11 @@ class Engine:
         check(self._lib.negf_last_info(self._ctx, int(m), _ptr(info)), "negf_last_info")
         return info[:m]
 
-    def warn_if_singular_dev(self, m, where):
-        """The *_dev entry points return no per-energy info: fetch it and warn like the host variants."""
+    def warn_if_singular_dev(self, m, where, grid_index=None):
+        """The *_dev entry points return no per-energy info: fetch it and warn like the host variants
+        (``grid_index``: the grid indices of the m energies when they are a shard of a larger grid)."""
         info = self.last_info_dev(m)
-        self._numerical(_lib.NEGF_ESINGULAR if np.any(info) else 0, info, where)
+        self._numerical(_lib.NEGF_ESINGULAR if np.any(info) else 0, info, where, grid_index)
 
     def last_iters_dev(self, handle, m, n_contacts):
         """(sweeps, converged) [m, n_contacts] of the fixed points run by the last call."""

@@ -141,16 +141,25 @@ def _spin_split(F, S, g):
     return [(sl, F[sl, sl], S[sl, sl], h) for sl, h in zip(sls, halves)]
 
 
+_split_depth = 0          # > 0 while the blocks of a split system are being integrated: split once, not recursively
+
+
 def _blockwise(F, S, g, call):
+    global _split_depth
+    if _split_depth:          # a spin block that happens to be block diagonal itself (e.g. diagonal F, S = I)
+        return None
     parts = _spin_split(F, S, g)
     if parts is None:
         return None
     out = np.zeros(F.shape, dtype=np.complex128)
+    _split_depth += 1
     try:
         for sl, Fb, Sb, gb in parts:
             out[sl, sl] = call(np.ascontiguousarray(Fb), np.ascontiguousarray(Sb), gb)
     except _NotBlockDiagonal:
         return None
+    finally:
+        _split_depth -= 1
     return out
 
 

@@ -105,6 +105,18 @@ class NEGFE:
         return (self.g.sigma(E, 0), self.g.sigma(E, -1))
 
     # ------------------------------------------------------------------ the density step
+    def saveMAT(self, matfile="out.mat"):
+        """MATLAB-format results file (scf.py:823-843): keys F (eV), sig1, sig2 (contact self-energies at the Fermi
+        level), S, fermi, qV, spin, den, conv -- the file ``transport.currentF`` reads.  Returns the Fock matrix
+        in the orthogonalised basis, X F X, as the reference does.  (The reference stores F in Hartree and writes
+        F * har_to_eV; here F is kept in eV.)"""
+        import scipy.io as io
+        sigma1, sigma2 = self.getSigma(self.fermi)
+        matdict = {"F": self.F, "sig1": sigma1, "sig2": sigma2, "S": self.S, "fermi": self.fermi, "qV": self.qV,
+                   "spin": self.spin, "den": self.P, "conv": self.convLevel}
+        io.savemat(matfile, matdict)
+        return self.X @ self.F @ self.X
+
     def FockToP(self):
         """Density matrix for the current Fock matrix (scfE.py:301-462).  Returns the sorted
         orbital energies and their occupations; ``self.P`` holds the density matrix."""

@@ -65,8 +65,17 @@ class surfGTest:
         self-energy matrix couples the blocks (integrate.py's block-diagonal fast path)."""
         if self.N != 2 * N:
             return None
+        # the halves (and the CONST providers they lower to) are kept with the object: GrInt / GrLessInt ask for
+        # them on every call, and creating / freeing device providers each time dominated small integrals
+        key = (N, tuple((id(sg), sg.shape, complex(np.sum(sg)), float(np.sum(np.abs(sg)))) for sg in self.sig))
+        cached = getattr(self, "_split_cache", None)
+        if cached is not None and cached[0] == key:
+            for h in cached[1] or ():
+                h.F = np.asarray(self.F)[h._sl, h._sl]; h.S = np.asarray(self.S)[h._sl, h._sl]
+            return cached[1]
         for sg in self.sig:
             if np.any(sg[:N, N:]) or np.any(sg[N:, :N]):
+                self._split_cache = (key, None)
                 return None
         halves = []
         for sl in (slice(0, N), slice(N, 2 * N)):
@@ -75,7 +84,9 @@ class surfGTest:
             h.indsList = self.indsList
             h.sig = [np.ascontiguousarray(sg[sl, sl]) for sg in self.sig]
             h._lowered = {}
+            h._sl = sl
             halves.append(h)
+        self._split_cache = (key, halves)
         return halves
 
     def _release(self):

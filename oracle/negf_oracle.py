@@ -328,21 +328,32 @@ def bethe_sigma_surface(E, H, Slist, Vlist, eta, conv=1e-5, mix=0.5, max_iter=10
 
 def bethe_atom_sigma(sigSurf, nInds):
     """surfGBethe.py:523-527 -- sum of the 9 surface directions minus those
-    attached to device neighbours.  A neighbour index >= 9 on the length-9 array
-    is clamped to 8, which is what a traced jnp index does in the reference
-    (out-of-range gather indices clamp in JAX); SURVEY.md section 8 a16."""
+    attached to device neighbours.  PINNED for neighbour lists inside 0..8 (the
+    reference's numpy twin surfG3D.py:417-433, tests/golden/ref_bethe.npz asm_*).
+    Outside that range the jax indexing rules of ``sigSurf[neighbor_idx]`` on the
+    length-9 array are followed (jax docs, "out-of-bounds indexing": retrieval
+    clamps; a negative index first wraps like numpy's): -9..-1 -> 0..8, anything
+    still outside clamps to 0 / 8.  Unverified against executed reference code
+    (jax is not installed); SURVEY.md section 8 a16."""
     out = np.sum(sigSurf[:9], axis=0)
     for nb in nInds:
-        out = out - sigSurf[min(max(int(nb), 0), 8)]
+        nb = int(nb)
+        if nb < 0:
+            nb += 9
+        out = out - sigSurf[min(max(nb, 0), 8)]
     return out
 
 
 def bethe_contact_sigma(E, N, atom_inds, atom_nInds, H, Slist, Vlist, eta,
-                        Xi=None, spin='r', **kw):
+                        Xi=None, spin='r', sigSurf=None, **kw):
     """surfGBethe.py:479-542 -- per-contact N x N (or 2N x 2N) self-energy:
     sig[ix_(Finds,Finds)] = sigma_atom (SET, not add); optional Xi sig Xi when
-    the .bethe overlap parameter sss == 0 (:530-533); spin kron (:536-539)."""
-    sigSurf, count, diff, countK = bethe_sigma_surface(E, H, Slist, Vlist, eta, **kw)
+    the .bethe overlap parameter sss == 0 (:530-533); spin kron (:536-539).
+    ``sigSurf``: given [9,9,9] surface self-energies (pinning the assembly against
+    the reference's numpy twin, which is handed the same set; the Xi branch of the
+    twin calls an undefined helper and cannot be pinned)."""
+    if sigSurf is None:
+        sigSurf, count, diff, countK = bethe_sigma_surface(E, H, Slist, Vlist, eta, **kw)
     sig = np.zeros((N, N), dtype=complex)
     for nInds, Finds in zip(atom_nInds, atom_inds):
         Finds = np.asarray(Finds)

@@ -27,10 +27,17 @@ def main(src, dst):
             for name, vals in counters.items():
                 out[kern][name] = sum(vals) / len(vals)
                 out[kern].setdefault("_launches", {})[name] = len(vals)
+    # which kernel sources the counters belong to: bench.py only quotes a profile taken on the tree's kernels
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaunegf_amd", "csrc")
+    out["_kernel_source_sha16"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
+                                   for f in sorted(os.listdir(csrc)) if f.endswith(".hip")}
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
     for kern, c in out.items():
+        if kern.startswith("_"):
+            continue
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             rd, wr = 2 * c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
             print(f"{kern[:70]:70s} read {rd/1e9:8.3f} GB  write {wr/1e9:8.3f} GB per launch")

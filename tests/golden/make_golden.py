@@ -267,6 +267,13 @@ def main():
             out[f"sg{size}_e{ie}_g"] = gm
             out[f"sg{size}_e{ie}_conv"] = np.array(conv_flag)
             out[f"sg{size}_e{ie}_iters"] = np.array(iters)
+            # the PRODUCTION start of the loop, g0 = inv(A) (surfG1D.py:287: solve(A, I)), handed to the same
+            # reference function: pins the start the product and the oracle use when no g_init is given
+            g0p = np.linalg.solve(A, np.eye(A.shape[0]))
+            gm, conv_flag, iters = sns["manual_iteration"](A, B, g0p, 1e-8, 0.1, 500)
+            out[f"sg{size}_e{ie}_g_invstart"] = gm
+            out[f"sg{size}_e{ie}_conv_invstart"] = np.array(conv_flag)
+            out[f"sg{size}_e{ie}_iters_invstart"] = np.array(iters)
 
     bns = {"np": np, "os": os}
     extract("tests/benchmark_sigma_parallelization.py",
@@ -361,6 +368,46 @@ def main():
             surf = quiet(at.sigma, float(E), None, 1e-5, 0.5)
             out[f"{name}_e{ie}_surface"] = np.array(surf)
             out[f"{name}_e{ie}_cluster"] = quiet(at.sigmaTot, float(E), 1e-5)
+    # ---- contact assembly: surfG3.sigma / sigmaTot (surfG3D.py:417-433, 435-463), the numpy
+    # twin of surfGBethe.py:479-575.  The object is created without its constructor (which needs Gaussian);
+    # everything the two methods read is injected: N, the per-contact atoms' orbital index lists and attached
+    # neighbour directions, the spin mode, and per contact an object whose sigma(E, i, conv) returns a given
+    # [9,9,9] set of surface self-energies (a seeded set -- the assembly is what is pinned here, the surface
+    # loop is pinned above).  Only lattices with Ssss != 0 (Au): for Ssss == 0 the twin calls a helper
+    # ``times`` that no module of the reference defines (NameError), so the Xi branch cannot be executed.
+    # Neighbour lists are subsets of 0..8 without repeats (the twin de-duplicates through set(), the jax
+    # version subtracts every listed entry).
+    class _GivenSurface:
+        def __init__(self, sig9):
+            self.sig9 = sig9
+        def sigma(self, E, i, conv):
+            return self.sig9.copy()
+    devA = object.__new__(g3["surfG3"])
+    devA.readBetheParams(os.path.join(REF, "Au"))
+    Nasm = 40
+    rng = np.random.default_rng(31)
+    inds_lists = [[list(range(0, 9)), list(range(9, 18))], [list(range(22, 31)), list(range(31, 40))]]
+    nind_lists = [[[0, 1, 2], [6, 7, 8, 3]], [[2, 5], []]]
+    sig9 = [np.array([(lambda p_: -1j * np.eye(9) * (0.5 + 0.1 * k) + (p_ + p_.T) * (0.2 - 0.1j))(rng.standard_normal((9, 9)) * 0.1)
+                      for k in range(9)]) for _ in range(2)]
+    out["asm_N"] = np.array(Nasm)
+    for c in range(2):
+        out[f"asm_c{c}_sig9"] = sig9[c]
+        for a_, (fi_, ni_) in enumerate(zip(inds_lists[c], nind_lists[c])):
+            out[f"asm_c{c}_a{a_}_inds"] = np.array(fi_)
+            out[f"asm_c{c}_a{a_}_nInds"] = np.array(ni_, dtype=int)
+    devA.N = Nasm
+    devA.gList = [_GivenSurface(sig9[0]), _GivenSurface(sig9[1])]
+    devA.indsLists = inds_lists
+    devA.nIndLists = nind_lists
+    devA.Xi = None
+    assert devA.Sdict['sss'] != 0
+    for spin in ("r", "u", "g"):
+        devA.spin = spin
+        out[f"asm_{spin}_sigma0"] = devA.sigma(0.3, 0)
+        out[f"asm_{spin}_sigma1"] = devA.sigma(0.3, 1)
+        out[f"asm_{spin}_sigmaTot"] = devA.sigmaTot(0.3)
+
     np.savez_compressed(os.path.join(OUT, "ref_bethe.npz"), **out)
     print("ref_bethe.npz:", len(out), "arrays")
 
@@ -388,6 +435,31 @@ def main():
     out["an_bisect_fermi"] = np.array(quiet(ans["bisectFermi"], Vv, Vc, Dv, Gam, 4.3, 1e-6, -1e6))
     np.savez_compressed(os.path.join(OUT, "ref_analytic_density.npz"), **out)
     print("ref_analytic_density.npz:", len(out), "arrays")
+    # ------------------ Fermi searches / integration-limit fitting (SURVEY f-1; density.py:821-1515, numpy bodies)
+    # The reference's own function bodies, AST-extracted and executed unmodified; the callables they use
+    # (densityComplexN / densityComplex / densityRealN / densityGridN, _compute_dos_at_energy, g.setF, g.sigmaTot)
+    # are the analytic spies of tests/fermi_probe_harness.py, which record every probe.  ``inv`` / ``eigh`` are
+    # bound to numpy's solve-with-identity / eigh: gauNEGF/utils.py:52-62 defines them as exactly those one-line
+    # jnp calls (calcEmin is the only user).
+    sys.path.insert(0, os.path.dirname(OUT))
+    import fermi_probe_harness as H
+    out = {}
+    rec = []
+    fns = {"np": np, "inv": lambda A: np.linalg.solve(A, np.eye(A.shape[0])), "eigh": np.linalg.eigh,
+           "FERMI_DEBUG": False}
+    for k in ("TEMPERATURE", "ADAPTIVE_INTEGRATION_TOL", "FERMI_CALCULATION_TOL", "FERMI_SEARCH_CYCLES",
+              "ENERGY_MIN", "MAX_CYCLES", "MAX_GRID_POINTS"):
+        fns[k] = getattr(cfg, k)
+    fns.update(H.make_spies(rec))
+    extract("gauNEGF/density.py", ["calcEmin", "integralFit", "integralFitNEGF", "calcFermiBisect",
+                                   "calcFermiSecant", "calcFermiMuller", "calcFermiPolyFit"], fns)
+    for tag, name, call in H.CASES:
+        rec.clear()
+        ret = quiet(call, fns[name], H.ProbeG(rec))
+        out[f"{tag}_probes"] = H.pack(rec)
+        out[f"{tag}_ret"] = H.scalars(ret)
+    np.savez_compressed(os.path.join(OUT, "ref_fermi_search.npz"), **out)
+    print("ref_fermi_search.npz:", len(out), "arrays;", {t: len(out[f"{t}_probes"]) for t, _, _ in H.CASES})
     print("numpy", np.__version__, "scipy", scipy.__version__)
 
 

@@ -1,7 +1,7 @@
 """
 Multi-process energy sharding on CPU (gloo, world_size 2): the N>1 path of
-gaunegf_amd.distributed -- cyclic shard, per-rank partial sums, ONE sum all-reduce
--- must reproduce the single-process integral.  The per-rank partial integral is
+gaunegf_amd.distributed -- cyclic shard, per-rank partial sums, ONE sum all-reduce; per-energy scalars by ONE all-gather of the
+shards -- must reproduce the single-process integral.  The per-rank partial integral is
 computed with the oracle here (no GPU in this container); on the GPU box the same
 ``sharded_sum`` wraps the HIP engine (integrate.py).
 """
@@ -39,10 +39,13 @@ def _worker(rank, world, port, q):
         gam = [1j * (g.sigma(0, i) - g.sigma(0, i).conj().T) for i in (0, 1)]
         Tm = D.sharded_map(lambda idx: np.array([oracle.transmission_restricted(e, F, S, st, gam[0], gam[1])
                                                  for e in E[idx]]), M)
+        # per-energy rows with a tail (T and four spin parts; DOS per site) and an empty shard (m < world)
+        rows = D.sharded_map(lambda idx: np.stack([np.asarray(idx) * 1.5, -np.asarray(idx, dtype=float)], axis=1), M, (2,))
+        one = D.sharded_map(lambda idx: np.array([7.25] * len(np.arange(1)[idx])), 1)
         # an empty shard (M < world) must still take part in the collective
         tiny = D.sharded_sum(lambda idx: oracle.GrInt(F, S, g, E[:1][idx], w[:1][idx]), 1)
         if rank == 0:
-            q.put((full, Tm, tiny))
+            q.put((full, Tm, tiny, rows, one))
     finally:
         D.disable()
         dist.destroy_process_group()
@@ -56,7 +59,7 @@ def test_sharded_integral_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    full, Tm, tiny = q.get(timeout=120)
+    full, Tm, tiny, rows, one = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -70,7 +73,9 @@ def test_sharded_integral_matches_single_process():
     st = g.sigmaTot(0.0)
     gam = [1j * (g.sigma(0, i) - g.sigma(0, i).conj().T) for i in (0, 1)]
     Tref = np.array([oracle.transmission_restricted(e, F, S, st, gam[0], gam[1]) for e in E])
-    assert np.array_equal(Tm, Tref)            # zero-filled all-reduce is exact
+    assert np.array_equal(Tm, Tref)            # an all-gather of the shards moves the values, exactly
+    assert np.array_equal(rows, np.stack([np.arange(M) * 1.5, -np.arange(M, dtype=float)], axis=1))
+    assert np.array_equal(one, np.array([7.25]))
     assert np.linalg.norm(tiny - oracle.GrInt(F, S, g, E[:1], w[:1])) < 1e-13
 
 

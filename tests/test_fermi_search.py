@@ -95,7 +95,7 @@ def test_searches_gpu_match_oracle_run(engine, monkeypatch, capsys):
 
 
 @pytest.mark.gpu
-def test_getFermi1DContact_gpu(engine, capsys):
+def test_getFermi1DContact_gpu(engine, monkeypatch, capsys):
     """Lead Fermi level of a 2-orbital chain: runs integralFit + calcFermi on the device-side
     CHAIN1D provider and returns a level inside the band with the requested filling."""
     from gaunegf_amd.surfG1D import surfG
@@ -109,5 +109,13 @@ def test_getFermi1DContact_gpu(engine, capsys):
     z = np.zeros((2, 2)); I2 = np.eye(2)
     g = surfG(F, S, [[0, 1], [N - 2, N - 1]], taus=[b.T, b], staus=[z, z], alphas=[a, a], aOverlaps=[I2, I2],
               betas=[b.T, b], bOverlaps=[z, z], eta=1e-4)
-    fermi, Emin, N1, N2 = D.getFermi1DContact(g, 1, ind=0, tol=1e-2, Eminf=-30.0, T=0.0, maxcycles=40)
+    tol = 1e-2
+    fermi, Emin, N1, N2 = D.getFermi1DContact(g, 1, ind=0, tol=tol, Eminf=-30.0, T=0.0, maxcycles=40)
     assert Emin < fermi < 3.0 and N1 >= 4 and N2 >= 8
+    # the filling at the returned level, recomputed with the ORACLE serving the same grids: one electron
+    # on the two-orbital lead cell (density.py:1037-1052 searches the single-cell lead with its own self-energy)
+    lead = oracle.Chain1DSigma(a, I2, [np.arange(2)], [b.T], [z], [a], [I2], [b.T], [z], eta=1e-6)
+    monkeypatch.setattr(D, "GrInt", oracle.GrInt)
+    P = np.real(D.densityRealN(a, I2, lead, -30.0, Emin, int(N2), 0, showText=False) +
+                D.densityComplexN(a, I2, lead, Emin, fermi, int(N1), 0.0, showText=False, method='legendre'))
+    assert abs(np.trace(P @ I2) - 1.0) < tol + 1e-3, np.trace(P @ I2)

@@ -141,14 +141,15 @@ def test_api_assertions_and_edges(engine):
 
 def test_workspace_is_stable_across_entry_points(engine):
     """One workflow on one grid -- GrInt, calculate_transmission, GrLessInt, DOS, GrInt -- must not re-allocate
-    the batch workspace between calls (the transmission needs two work areas per energy; the workspace is
-    sized for that from the first call on)."""
+    the batch workspace between calls: the transmission needs two work areas per energy, and once it has run on
+    a context the workspace is sized for that (contexts that only integrate keep the single-grid size)."""
     from gaunegf_amd.integrate import GrInt, GrLessInt
     from gaunegf_amd.transport import SigmaCalculator, calculate_transmission, calculate_dos
     N = 72
     F, S, g_dev, g_ref = _const_provider(N, 19)
     E = np.linspace(-1.0, 1.0, 37); w = np.full(37, 2.0 / 37)
     sc = SigmaCalculator(g_dev.sig[0], g_dev.sig[1])
+    calculate_transmission(F, S, sc, E[:3])              # from here on the context knows the workflow
     GrInt(F, S, g_dev, E, w)
     b0 = engine.get_batch()
     assert b0 >= 2 * len(E)
@@ -614,15 +615,33 @@ def test_bethe_raw_free_running(engine):
         assert rel_fro(out[k], ref) < 10 * 1e-5
 
 
-def test_bethe_contact_fermi_level(engine, capsys):
-    """surfGBAt.calcFermi (surfGBethe.py:1158-1188): contour + real-axis integrals of the 13-site
-    cluster with the Bethe self-energy; the electron count at the returned level matches ne."""
+def test_bethe_contact_fermi_level(engine, monkeypatch, capsys):
+    """surfGBAt.calcFermi (surfGBethe.py:1158-1188): contour + real-axis integrals of the 13-site cluster with
+    the Bethe self-energy.  The electron count on the centre site at the returned level -- recomputed with the
+    ORACLE serving the same grids (oracle.GrInt, oracle Bethe loops) -- must equal ne within the search tolerance."""
     import gaunegf_amd.density as D
+    from gaunegf_amd.config import ENERGY_MIN
     at, H0, Sl, Vl = _bethe_atom()
     at.eta = 1e-4
-    ne = 5.5                                                    # Au: 11 electrons / 2 (surfGBethe.py:208)
-    Ef = at.calcFermi(ne, tol=5e-2)
-    assert np.isfinite(Ef) and -20.0 < Ef < 20.0
+    ne, tol = 5.5, 5e-2                                         # Au: 11 electrons / 2 (surfGBethe.py:208)
+    orbs = D._orbital_energies(at.F, at.S)
+    f0 = (orbs[int(ne) - 1] + orbs[int(ne)]) / 2
+    Emin, N1, N2 = D.integralFit(at.F, at.S, at, f0, ENERGY_MIN, tol, at.T, maxN=1000)
+    Ef = D.calcFermi(at, ne, Emin, max(orbs), f0, N1, N2, ENERGY_MIN, at.T, tol, 1000, nOrbs=9)[0]
+    assert Ef == at.calcFermi(ne, tol=tol)                     # the method is exactly this sequence
+    assert Emin < Ef < max(orbs)
+
+    class RefCluster:                                           # the same cluster served by the numpy oracle
+        F, S = at.F, at.S
+        def sigmaTot(self, E, conv=None):
+            return oracle.bethe_cluster_sigma_total(E, H0, Sl, Vl, at.eta)
+    ref = RefCluster()
+    monkeypatch.setattr(D, "GrInt", oracle.GrInt)
+    P = np.real(D.densityRealN(at.F, at.S, ref, ENERGY_MIN, Emin, int(N2), 0, showText=False) +
+                D.densityComplexN(at.F, at.S, ref, Emin, Ef, int(N1), at.T, showText=False, method='legendre'))
+    monkeypatch.undo()
+    n_center = np.real(D._count(P, at.S, 9))
+    assert abs(n_center - ne) < tol + 5e-3, (n_center, Ef)
     # cross-check the vectorised cluster self-energy against the per-energy protocol call
     Es = np.array([-3.0, 0.5])
     both = at.sigmaTot_batch(Es)
@@ -675,6 +694,37 @@ def test_bethe_contact_assembly_and_integrals(engine, name):
         assert rel_fro(GrLessInt(F, S, g, Eg, wg, ind), oracle.GrLessInt(F, S, ref, Eg, wg, ind)) < TOL
 
 
+@pytest.mark.parametrize("spin", ["r", "u"])
+def test_bethe_contact_assembly_given_device_surface(engine, spin):
+    """SURVEY a16.  The oracle's contact assembly is pinned to the reference's numpy twin (surfG3D.py:417-433,
+    test_oracle_golden.py::test_bethe_contact_assembly_vs_reference_numpy_twin); handed the DEVICE's own surface
+    self-energies it must reproduce the device's assembled contact matrices -- also for attached directions
+    outside 0..8, where both follow the jax indexing rules (wrap, then clamp)."""
+    from gaunegf_amd.surfGBethe import surfGB
+    N = 60
+    coords, orbMap, orbTyp = _bethe_device("Au", N)
+    F, S = random_system(N, 78)
+    lat = os.path.join(os.path.dirname(__file__), "golden", "Au")
+    g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0, spin=spin)
+    g.force_iters = 20
+    for at in g.gList:
+        at.force_iters = 20                              # the per-atom objects run the same fixed trip count
+    assert g.Sdict['sss'] != 0
+    for variant in range(2):
+        if variant == 1:                                 # out-of-range and negative attached directions
+            g.nIndLists = [[[0, 9], [-1, 3, 11]] + [list(v) for v in g.nIndLists[0][2:]], [list(v) for v in g.nIndLists[1]]]
+            g._version += 1                              # the lowered provider is rebuilt
+        for E in (-4.0, 0.5):
+            tot = 0
+            for i in (0, 1):
+                s9 = g.gList[i].sigma(E)
+                ref = oracle.bethe_contact_sigma(E, N, g.indsLists[i], g.nIndLists[i], None, None, None, 1e-6, spin=spin, sigSurf=s9)
+                got = g.sigma(E, i)
+                assert got.shape == ref.shape and rel_fro(got, ref) < 1e-13, (variant, E, i)
+                tot = tot + ref
+            assert rel_fro(g.sigmaTot(E), tot) < 1e-13
+
+
 # --------------------------------------------------------------------------- #
 # density front-ends end to end, and full-size properties
 # --------------------------------------------------------------------------- #
@@ -702,6 +752,51 @@ def test_density_front_ends(engine):
     # trace of P S counts electrons: positive and below N
     ne = np.real(np.trace(P @ S))
     assert 0 < ne < 40
+
+
+def test_saveMAT_round_trip_through_currentF(engine, tmp_path, capsys):
+    """NEGFE.saveMAT (scf.py:823-843) writes the keys F, sig1, sig2, S, fermi, qV, spin, den, conv;
+    transport.currentF (transport.py:847-875) reads that file back: the current from the file equals the current
+    computed from the in-memory matrices, and the oracle's value."""
+    import scipy.io as io
+    from gaunegf_amd.scfE import NEGFE
+    from gaunegf_amd.transport import currentF, current
+    N = 24
+    F, S, g_dev, g_ref = _const_provider(N, 12, nc=4)
+    sys_ = NEGFE(F, S, g_dev, ne=2 * 9, spin='r', T=300.0, Eminf=-60.0)
+    sys_.setIntegralLimits(N1=24, N2=8, Nnegf=8, tol=1e-4, Emin=-7.0)
+    sys_.setVoltage(0.2, fermi=0.1)
+    sys_.FockToP()
+    fn = str(tmp_path / "out.mat")
+    Fbar = sys_.saveMAT(fn)
+    assert rel_fro(Fbar, sys_.X @ F @ sys_.X) < 1e-14
+    m = io.loadmat(fn)
+    for k in ("F", "sig1", "sig2", "S", "fermi", "qV", "spin", "den", "conv"):
+        assert k in m, k
+    assert np.array_equal(m["F"], F) and np.array_equal(m["S"], S) and m["spin"][0] == 'r'
+    assert m["fermi"][0, 0] == 0.1 and m["qV"][0, 0] == 0.2 and rel_fro(m["den"], sys_.P) == 0.0
+    s1, s2 = sys_.getSigma(0.1)
+    assert np.array_equal(m["sig1"], s1) and np.array_equal(m["sig2"], s2)
+    I_file = currentF(fn, dE=0.01, T=300.0)
+    I_mem = current(F, S, s1, s2, 0.1, 0.2, 300.0, 'r', dE=0.01)
+    assert I_file == I_mem and I_file != 0.0
+    # oracle: the same grid and quadrature with the numpy transmission
+    from gaunegf_amd.transport import calculate_current, SigmaCalculator
+    import gaunegf_amd.transport as TR
+    Eg = []
+    orig = TR.calculate_transmission
+    def spy(F_, S_, sc_, energies, spin=None, **kw):
+        Eg.append(np.asarray(energies)); return orig(F_, S_, sc_, energies, spin=spin, **kw)
+    TR.calculate_transmission = spy
+    try:
+        calculate_current(F, S, SigmaCalculator(s1, s2), 0.1, 0.2, 300.0, 'r', 0.01)
+    finally:
+        TR.calculate_transmission = orig
+    sc = SigmaCalculator(s1, s2)
+    Tref = np.array([oracle.transmission_restricted(e, F, S, sc.get_sigma_total(e), sc.get_gamma(e, 0), sc.get_gamma(e, -1))
+                     for e in Eg[0]])
+    Tdev = orig(F, S, sc, Eg[0], spin='r')
+    assert np.max(np.abs(Tdev - Tref)) < 1e-9 * max(1.0, np.max(np.abs(Tref)))
 
 
 def test_fock_to_p_density_step(engine, capsys):
@@ -824,6 +919,34 @@ def test_config_C3_shape(engine):
     G = GrBatch(F, S, g_dev, E[sub[:2]])
     for k in range(2):
         assert rel_fro(G[k], oracle.gr_point(g_ref.sigmaTot(E[sub[k]]), E[sub[k]], F, S)) < TOL
+
+
+def test_config_C3_free_running_at_the_sweep_cap(engine):
+    """C3 at full size with the PRODUCTION stopping rule (surfG1D.py:271-288): 69 % of the headline grid's fixed
+    points stop at the 2000-sweep cap, where the iterate is not a fixed point.  Six such energies and two that
+    converge, picked from a 32-point probe of the 2000-point grid, against the oracle: sweep counts (+-1 only where
+    the threshold is crossed; at the cap both run exactly 2000), Sigma(E), and GrInt on that sub-grid.  The grid is
+    evaluated twice -- the second launch runs longest-first in the order learned from the first -- and must
+    reproduce Sigma and the counts bit for bit."""
+    from gaunegf_amd.integrate import GrInt
+    F, S, g_dev, g_ref = _chain_system(500, 50, 3, 1e-4)
+    E, w = oracle.real_axis_grid(-2.0, 2.0, 2000, 0.0)
+    probe = np.arange(3, 2000, 63)
+    _, it, _ = g_dev.sigma_batch(E[probe])
+    at_cap = it.max(axis=1) >= 2000
+    assert at_cap.sum() >= 6 and (~at_cap).sum() >= 2, it.max(axis=1)
+    sub = np.concatenate([probe[at_cap][:6], probe[~at_cap][:2]])
+    sig, iters, cv = g_dev.sigma_batch(E[sub])
+    sig2, iters2, cv2 = g_dev.sigma_batch(E[sub])                 # learned (longest-first) launch order
+    assert np.array_equal(iters, iters2) and np.array_equal(cv, cv2) and np.array_equal(sig, sig2)
+    for k, e in enumerate(E[sub]):
+        ref = g_ref.sigmaTot(e)
+        for c in (0, 1):
+            cnt = g_ref.last_iters[(complex(e), c)][0]
+            assert abs(int(iters[k, c]) - cnt) <= (0 if cnt >= 2000 else 1), (e, c, int(iters[k, c]), cnt)
+        capped = max(g_ref.last_iters[(complex(e), c)][0] for c in (0, 1)) >= 2000
+        assert rel_fro(sig[k], ref) < (1e-7 if capped and iters[k].min() >= 2000 else 10 * 1e-5), (e, iters[k])
+    assert rel_fro(GrInt(F, S, g_dev, E[sub], w[sub]), oracle.GrInt(F, S, g_ref, E[sub], w[sub])) < 1e-4
 
 
 def test_config_C4_shape(engine):

@@ -144,6 +144,12 @@ def test_chain_fixed_point_vs_reference_manual_iteration(golden_num, size):
         assert count == int(g[f"sg{size}_e{ie}_iters"])
         assert (diff <= 1e-8) == bool(g[f"sg{size}_e{ie}_conv"])
         assert np.max(np.abs(gi - g[f"sg{size}_e{ie}_g"])) < 1e-10      # the reference's own bar (:123)
+        # ... and from the production start g0 = inv(A) (surfG1D.py:287), which the same reference function
+        # was handed through its g_init argument: the oracle's default start
+        gi, count, diff = oracle.chain1d_g(E, al, Sa, be, Sb, 1e-4, conv=1e-8, relFactor=0.1, max_iter=500)
+        assert count == int(g[f"sg{size}_e{ie}_iters_invstart"])
+        assert (diff <= 1e-8) == bool(g[f"sg{size}_e{ie}_conv_invstart"])
+        assert np.max(np.abs(gi - g[f"sg{size}_e{ie}_g_invstart"])) < 1e-10
 
 
 def test_chain_sigma_vs_reference_benchmark(golden_num):
@@ -226,6 +232,44 @@ def test_bethe_setup_and_loops_vs_reference_numpy_twin(golden_bethe, name):
         assert rel_fro(surf, g[f"{name}_e{ie}_surface"]) < 1e-12, (name, E, count)
         cl = oracle.bethe_cluster_sigma_total(float(E), H0, Sl, Vl, eta, sigK=sigK)
         assert rel_fro(cl, g[f"{name}_e{ie}_cluster"]) < 1e-14
+
+
+def _asm_lists(g, c):
+    inds, nInds = [], []
+    a = 0
+    while f"asm_c{c}_a{a}_inds" in g:
+        inds.append(list(g[f"asm_c{c}_a{a}_inds"])); nInds.append([int(v) for v in g[f"asm_c{c}_a{a}_nInds"]])
+        a += 1
+    return inds, nInds
+
+
+@pytest.mark.parametrize("spin", ["r", "u", "g"])
+def test_bethe_contact_assembly_vs_reference_numpy_twin(golden_bethe, spin):
+    """surfG3.sigma / sigmaTot (surfG3D.py:417-433, 435-463, executed by make_golden.py with
+    injected surface self-energies) pin the oracle's contact assembly -- atom blocks SET at ix_(inds, inds),
+    the 9 directions minus the attached ones, the spin expansion -- for neighbour lists inside 0..8."""
+    g = golden_bethe
+    N = int(g["asm_N"])
+    tot = 0
+    for c in (0, 1):
+        inds, nInds = _asm_lists(g, c)
+        got = oracle.bethe_contact_sigma(0.3, N, inds, nInds, None, None, None, 0.0, spin=spin, sigSurf=g[f"asm_c{c}_sig9"])
+        ref = g[f"asm_{spin}_sigma{c}"]
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) < 1e-15 * max(1.0, np.max(np.abs(ref)))
+        tot = tot + got
+    assert np.max(np.abs(tot - g[f"asm_{spin}_sigmaTot"])) < 1e-15 * np.max(np.abs(tot))
+
+
+def test_bethe_atom_sigma_index_rules():
+    """Outside 0..8 the jax indexing rules of the reference's ``sigSurf[neighbor_idx]`` are followed: a negative
+    index wraps, what is still outside clamps (unverified against executed reference code)."""
+    rng = np.random.default_rng(3)
+    s9 = rng.standard_normal((9, 9, 9)) + 1j * rng.standard_normal((9, 9, 9))
+    full = np.sum(s9, axis=0)
+    assert np.allclose(oracle.bethe_atom_sigma(s9, [-1]), full - s9[8])
+    assert np.allclose(oracle.bethe_atom_sigma(s9, [-9, 2]), full - s9[0] - s9[2])
+    assert np.allclose(oracle.bethe_atom_sigma(s9, [11]), full - s9[8])
+    assert np.allclose(oracle.bethe_atom_sigma(s9, [-12]), full - s9[0])
 
 
 def test_analytic_density_vs_reference_and_grid_integrals(golden_analytic, capsys):
