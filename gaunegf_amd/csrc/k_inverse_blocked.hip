@@ -306,11 +306,14 @@ __device__ __forceinline__ void gj_update_item(const cplx* __restrict__ Pt, int 
     for (int r = 0; r < 4; ++r) c0[r] = wcol[(size_t)min(ti0 * 16 + fk + 4 * r, n - 1) * n];
     for (int ti = ti0; ti < ti1; ++ti) {
         const unsigned m = rowmask[ti >> 1] >> ((ti & 1) * 16 + fk);    // bit 4r: row fk + 4r of this tile
-        d4 accr, acci;
+        // complex product in 3M form: s1 = sum pr qr, s2 = sum pi qi, s3 = sum (pr + pi)(qr + qi); the old tile seeds
+        // s1 (real part) and s3 (real + imaginary part): re = s1 - s2, im = s3 - s1 - s2.  Three matrix instructions per
+        // k-step instead of four: the FP64 matrix instruction is what these kernels' time is made of.
+        d4 accr, acci, accs = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool z = (m >> (4 * r)) & 1u;
-            accr[r] = z ? 0.0 : c0[r].x; acci[r] = z ? 0.0 : c0[r].y;
+            accr[r] = z ? 0.0 : c0[r].x; acci[r] = z ? 0.0 : c0[r].x + c0[r].y;
         }
         const int tn = min(ti + 1, ti1 - 1);
 #pragma unroll
@@ -320,14 +323,13 @@ __device__ __forceinline__ void gj_update_item(const cplx* __restrict__ Pt, int 
         for (int ks = 0; ks < KS; ++ks) {
             const cplx pa = pcol[(size_t)ks * 4 * rows16];
             accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].x, accr, 0, 0, 0);
-            accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, -qf[ks].y, accr, 0, 0, 0);
-            acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x, qf[ks].y, acci, 0, 0, 0);
-            acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].x, acci, 0, 0, 0);
+            accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.y, qf[ks].y, accs, 0, 0, 0);
+            acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa.x + pa.y, qf[ks].x + qf[ks].y, acci, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + fk + 4 * r;
-            if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+            if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r] - accs[r], acci[r] - accr[r] - accs[r]);
         }
     }
 }
@@ -786,11 +788,11 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
 #pragma unroll
                         for (int r = 0; r < 4; ++r) cv[0][r] = crow[r][colc];
                     }
-                    d4 accr, acci;
+                    d4 accr, acci, accs = {0, 0, 0, 0};                  // 3M form, see gj_update_item
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const cplx c = cv[CB == WT ? t : 0][r];
-                        accr[r] = keep[r] ? c.x : 0.0; acci[r] = keep[r] ? c.y : 0.0;
+                        accr[r] = keep[r] ? c.x : 0.0; acci[r] = keep[r] ? c.x + c.y : 0.0;
                     }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
@@ -799,14 +801,13 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
                         cplx qb = qwin[(NBI % 4 == 0 ? kq : min(kq, NBI - 1)) * WIN + t * 16 + fi];
                         if (NBI % 4 != 0 && kq >= NBI) qb = cmake(0.0, 0.0);
                         accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.x, accr, 0, 0, 0);
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, -qb.y, accr, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.y, acci, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.x, acci, 0, 0, 0);
+                        accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.y, accs, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x + pa[ks].y, qb.x + qb.y, acci, 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = ti * 16 + fk + 4 * r;
-                        if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                        if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r] - accs[r], acci[r] - accr[r] - accs[r]);
                     }
                 }
             }
@@ -894,21 +895,20 @@ __global__ __launch_bounds__(LA_THREADS) void gj_window_la_kernel(
                 if ((tmask >> t) & 1u) {                             // (uniform)
                     const int col = c0 + t * 16 + fi;
                     const bool col_store = col < n && col < c0 + cw;
-                    d4 accr, acci;
+                    d4 accr, acci, accs = {0, 0, 0, 0};                  // 3M form, see gj_update_item
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { accr[r] = keep[r] ? cv[t][r].x : 0.0; acci[r] = keep[r] ? cv[t][r].y : 0.0; }
+                    for (int r = 0; r < 4; ++r) { accr[r] = keep[r] ? cv[t][r].x : 0.0; acci[r] = keep[r] ? cv[t][r].x + cv[t][r].y : 0.0; }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         const cplx qb = qwin[(ks * 4 + fk) * WIN + t * 16 + fi];
                         accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.x, accr, 0, 0, 0);
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, -qb.y, accr, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.y, acci, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.x, acci, 0, 0, 0);
+                        accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.y, accs, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x + pa[ks].y, qb.x + qb.y, acci, 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = ti * 16 + fk + 4 * r;
-                        if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r], acci[r]);
+                        if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r] - accs[r], acci[r] - accr[r] - accs[r]);
                     }
                 }
             }
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
     };
     for (int ib = 0; ib < nblk; ++ib) {
         const int buf = ib & 1;
-        d4 cr[2], ci[2];
+        d4 cr[2], ci[2], cs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // 3M form (see gj_update_item): cr = s1, cs = s2, ci = s3
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of P'[ib] (not in hipcc's bookkeeping)
         __syncthreads();                  // (vmcnt(0): the Q fragments too, before the first store to the block)
 #pragma unroll
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool z = pflag[min(ib * 64 + wr + a * 16 + fk + 4 * r, n - 1)] != 0;
-                cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].y;
+                cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].x + cv[a][r].y;
             }
         const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
         cplx af[2][2];
@@ -1103,19 +1103,18 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
 #pragma unroll
                 for (int a = 0; a < 2; ++a) af[cur ^ 1][a] = ab[a * 16 * CU_AP + (ks + 1) * 4];
             }
+            const double qs = qf[ks].x + qf[ks].y;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x, qf[ks].x, cr[a], 0, 0, 0);
-                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x, qf[ks].y, ci[a], 0, 0, 0);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[cur][a].y, qf[ks].y, cr[a], 0, 0, 0);
-                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].y, qf[ks].x, ci[a], 0, 0, 0);
+                cs[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].y, qf[ks].y, cs[a], 0, 0, 0);
+                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x + af[cur][a].y, qs, ci[a], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) { sr[a] = cr[a]; si[a] = ci[a]; }
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sr[a][r] = cr[a][r] - cs[a][r]; si[a][r] = ci[a][r] - cr[a][r] - cs[a][r]; }
     }
     store_block(nblk - 1);
 }
@@ -1166,22 +1165,62 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     }
     static int winla = -1;
     if (winla < 0) { const char* e = getenv("NEGF_GJ_WINLA"); winla = e ? atoi(e) : 1; }
-    hipLaunchKernelGGL(gj_state_init_kernel, dim3(nb), dim3(256), 0, st, n, piv, info);
     const int nblk = (n + 63) / 64;
-    for (int c0 = 0; c0 < n; c0 += WIN) {
-        const int cw = min(WIN, n - c0);
-        if (NBI == 16 && RPT == 1 && winla)
-            hipLaunchKernelGGL(gj_window_la_kernel<16>, dim3(nb), dim3(LA_THREADS), smem, st, n, A, stride, piv, info, c0, cw,
-                               c0 == WIN ? d_stamps : (unsigned long long*)nullptr);
-        else
-            hipLaunchKernelGGL(kern, dim3(nb), dim3(PT), smem, st, n, A, stride, piv, info, c0, cw,
-                               c0 == WIN ? d_stamps : (unsigned long long*)nullptr);
-        if (nblk > 1)
-            hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((nb + 7) / 8) * (nblk - 1)), dim3(CU_THREADS), 0, st,
-                               n, nb, A, stride, (const int*)piv, c0, cw);
+    // the chain of one group of matrices: per window the panel kernel (one workgroup per matrix: a latency chain
+    // that covers at most `count` CUs) and the column-block update (throughput-bound), then the gather
+    auto chain = [&](hipStream_t s, int first, int count) {
+        cplx* Ag = A + (size_t)first * stride; cplx* Bg = B + (size_t)first * stride;
+        int* pg = piv + (size_t)first * 2 * n; int* ig = info + first;
+        hipLaunchKernelGGL(gj_state_init_kernel, dim3(count), dim3(256), 0, s, n, pg, ig);
+        for (int c0 = 0; c0 < n; c0 += WIN) {
+            const int cw = min(WIN, n - c0);
+            unsigned long long* stp = (c0 == WIN && first == 0) ? d_stamps : (unsigned long long*)nullptr;
+            if (NBI == 16 && RPT == 1 && winla)
+                hipLaunchKernelGGL(gj_window_la_kernel<16>, dim3(count), dim3(LA_THREADS), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
+            else
+                hipLaunchKernelGGL(kern, dim3(count), dim3(PT), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
+            if (nblk > 1)
+                hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 1)), dim3(CU_THREADS), 0, s,
+                                   n, count, Ag, stride, (const int*)pg, c0, cw);
+        }
+        hipLaunchKernelGGL(gj_gather_kernel, dim3(n, count), dim3(256), 0, s, n, (const cplx*)Ag, Bg, stride,
+                           (const int*)pg, (const int*)ig);
+    };
+    // Small batches -- what the energy grid of BASELINE's multi-GPU configurations leaves one GPU: C4 sharded 8
+    // ways is 61 matrices of N = 800, C5 128 of N = 1000 -- cannot cover the chip with one panel workgroup per
+    // matrix, and window k+1 waits for the column update of window k.  The batch is then cut into up to four
+    // groups on streams of their own: while one group factors a panel (a few CUs), the column updates of the
+    // others use the rest of the chip: 61 x N = 800 24.5 -> 30.5 TF, 128 x N = 1000 34.9 -> 40.0 TF.  At full batch both
+    // kernels fill the chip by themselves and the groups mostly run in lockstep: + 2 % (1000 x N = 500 33.1 -> 33.8 TF).
+    static int split_max = -1;
+    if (split_max < 0) { const char* e = getenv("NEGF_GJ_SPLIT_MAX"); split_max = e ? atoi(e) : 1 << 30; }
+    const int groups = (nb <= split_max && !d_stamps) ? std::max(1, std::min(4, nb / 12)) : 1;
+    if (groups == 1) {
+        chain(st, 0, nb);
+    } else {
+        constexpr int MAXG = 4;
+        static hipStream_t side[MAXG - 1] = {nullptr, nullptr, nullptr};
+        static hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {nullptr, nullptr, nullptr};
+        if (!ev_fork) {
+            (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+            for (int g = 0; g < MAXG - 1; ++g) {
+                (void)hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking);
+                (void)hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming);
+            }
+        }
+        (void)hipEventRecord(ev_fork, st);
+        const int per = (nb + groups - 1) / groups;
+        for (int g = 1; g < groups; ++g) {
+            const int first = g * per, count = std::min(per, nb - first);
+            if (count <= 0) continue;
+            (void)hipStreamWaitEvent(side[g - 1], ev_fork, 0);
+            chain(side[g - 1], first, count);
+            (void)hipEventRecord(ev_join[g - 1], side[g - 1]);
+        }
+        chain(st, 0, std::min(per, nb));
+        for (int g = 1; g < groups; ++g)
+            if (g * per < nb) (void)hipStreamWaitEvent(st, ev_join[g - 1], 0);
     }
-    hipLaunchKernelGGL(gj_gather_kernel, dim3(n, nb), dim3(256), 0, st, n, (const cplx*)A, B, stride,
-                       (const int*)piv, (const int*)info);
     if (d_stamps) {
         (void)hipStreamSynchronize(st);
         unsigned long long h[64];

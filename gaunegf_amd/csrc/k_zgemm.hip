@@ -4,8 +4,11 @@
 //
 // used for the dense products of the lesser Green's function G Gamma G^H
 // (integrate.py:81) and of the transmission Gamma_L G Gamma_R (transport.py:156,
-// 176).  A complex product is four real MFMA chains per 16x16 tile:
-//   Cr += Ar*Br ; Cr += (-Ai)*Bi ; Ci += Ar*Bi ; Ci += Ai*Br
+// 176).  A complex product is THREE real MFMA chains per 16x16 tile ("3M"):
+//   S1 += Ar*Br ; S2 += Ai*Bi ; S3 += (Ar+Ai)*(Br+Bi)   =>   Cr = S1 - S2 ,  Ci = S3 - S1 - S2
+// (one addition per operand fragment and k-step instead of a fourth matrix instruction; the FP64 matrix
+// instruction holds its SIMD's vector issue for most of its 64 cycles, so matrix-pipe time is the kernel's time;
+// the result differs from the four-product form by a few ulp of |A||B|, five orders inside the 1e-8 bar).
 // Fragment layout of v_mfma_f64_16x16x4_f64 (guide section 3):
 //   A operand: lane l holds A[i = l&15][k = l>>4]       (one f64 per lane)
 //   B operand: lane l holds B[k = l>>4][j = l&15]
@@ -23,7 +26,7 @@ static constexpr int ZG_BM = 64, ZG_BN = 64, ZG_BK = 16;
 static constexpr int ZG_APITCH = ZG_BK + 1;     // odd pitch: 16 rows -> 16 distinct 16-B slots
 static constexpr int ZG_BPITCH = ZG_BN + 1;
 
-__global__ __launch_bounds__(256) void zgemm_mfma_kernel(
+__global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
     int M, int N, int K,
     const cplx* __restrict__ Aall, int lda, size_t strideA,
     const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
@@ -42,11 +45,11 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;   // wave tile origin in the block tile
     const int fi = lane & 15, fk = lane >> 4;
 
-    d4 accr[2][2], acci[2][2];
+    d4 s1[2][2], s2[2][2], s3[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) { accr[a][c] = (d4){0, 0, 0, 0}; acci[a][c] = (d4){0, 0, 0, 0}; }
+        for (int c = 0; c < 2; ++c) { s1[a][c] = (d4){0, 0, 0, 0}; s2[a][c] = (d4){0, 0, 0, 0}; s3[a][c] = (d4){0, 0, 0, 0}; }
 
     // edge blocks: sub-tiles that start beyond M or N do no work (n = 200 pads to 208, not 256)
     bool va[2], vc[2];
@@ -106,15 +109,16 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
             for (int a = 0; a < 2; ++a) af[a] = As[(wr + a * 16 + fi) * ZG_APITCH + ks + fk];
 #pragma unroll
             for (int c = 0; c < 2; ++c) bf[c] = Bs[(ks + fk) * ZG_BPITCH + wc + c * 16 + fi];
+            const double as_[2] = {af[0].x + af[0].y, af[1].x + af[1].y};
+            const double bs_[2] = {bf[0].x + bf[0].y, bf[1].x + bf[1].y};
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     if (!(va[a] && vc[c])) continue;       // 16x16 sub-tile entirely outside the matrix (wave-uniform)
-                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].x, accr[a][c], 0, 0, 0);
-                    accr[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af[a].y, bf[c].y, accr[a][c], 0, 0, 0);
-                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].y, acci[a][c], 0, 0, 0);
-                    acci[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf[c].x, acci[a][c], 0, 0, 0);
+                    s1[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].x, bf[c].x, s1[a][c], 0, 0, 0);
+                    s2[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a].y, bf[c].y, s2[a][c], 0, 0, 0);
+                    s3[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(as_[a], bs_[c], s3[a][c], 0, 0, 0);
                 }
         }
         __syncthreads();
@@ -128,18 +132,20 @@ __global__ __launch_bounds__(256) void zgemm_mfma_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int gi = row0 + wr + a * 16 + fk + 4 * r;
                 const int gj = col0 + wc + c * 16 + fi;
-                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(accr[a][c][r], acci[a][c][r]);
+                if (gi < M && gj < N)
+                    C[(size_t)gi * ldc + gj] = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
             }
 }
 
 // ---- flexible-block version for shapes the 64 x 64 block tile pads badly (n = 200: 13 tiles of 16 per
 // dimension fill 4 x 4 blocks of 64 only to 66 %, and an edge block costs almost what a full one does:
 // measured 34 TF at n = 200 against 53 TF at n = 192).  A block covers tm x tn sub-tiles of 16 x 16 with
-// tm, tn <= 7, the sub-tile counts of the blocks of a dimension differ by at most one (13 -> 7 + 6), so no
-// block is mostly padding; the block's sub-tiles are dealt to 8 waves, up to 7 each (112 accumulator VGPRs),
-// every sub-tile reads its own A and B fragment from LDS (one read each per 4 MFMAs).
-static constexpr int ZF_MAXT = 7, ZF_THREADS = 512, ZF_WAVES = 8;
-static constexpr int ZF_ROWS = ZF_MAXT * 16;                    // 112
+// tm, tn <= 5, the sub-tile counts of the blocks of a dimension differ by at most one (13 -> 5 + 4 + 4), so no
+// block is mostly padding; the block's sub-tiles are dealt to 8 waves, up to 4 each (3M: 96 accumulator VGPRs;
+// blocks of 7 x 7 sub-tiles -- 7 per wave, 168 accumulator VGPRs -- spilled and ran 40.3 TF at n = 200 against
+// 43.5 TF), every sub-tile reads its own A and B fragment from LDS (one read each per 3 MFMAs).
+static constexpr int ZF_MAXT = 5, ZF_THREADS = 512, ZF_WAVES = 8;
+static constexpr int ZF_ROWS = ZF_MAXT * 16;                    // 80
 static constexpr int ZF_APITCH = ZG_BK + 1, ZF_BPITCH = ZF_ROWS + 1;
 
 __host__ __device__ inline void zf_block_range(int tiles, int nblk, int b, int* t0, int* tn)
@@ -168,11 +174,11 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fk = lane >> 4;
 
-    d4 accr[ZF_MAXT], acci[ZF_MAXT];
+    d4 s1[ZF_MAXT], s2[ZF_MAXT], s3[ZF_MAXT];   // 3M accumulators (see the head of the file)
     int toffA[ZF_MAXT], toffB[ZF_MAXT];          // LDS offsets of the sub-tile's A rows / B columns
 #pragma unroll
     for (int s = 0; s < ZF_MAXT; ++s) {
-        accr[s] = (d4){0, 0, 0, 0}; acci[s] = (d4){0, 0, 0, 0};
+        s1[s] = (d4){0, 0, 0, 0}; s2[s] = (d4){0, 0, 0, 0}; s3[s] = (d4){0, 0, 0, 0};
         const int t = wave + s * ZF_WAVES;
         const int ti = t < ntiles ? t / tn : 0, tj = t < ntiles ? t - (t / tn) * tn : 0;
         toffA[s] = (ti * 16 + fi) * ZF_APITCH + fk;
@@ -218,10 +224,9 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
                 if (wave + s * ZF_WAVES < ntiles) {              // wave-uniform
                     const cplx af = As[toffA[s] + ks];
                     const cplx bf = Bs[toffB[s] + ks * ZF_BPITCH];
-                    accr[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, bf.x, accr[s], 0, 0, 0);
-                    accr[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af.y, bf.y, accr[s], 0, 0, 0);
-                    acci[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, bf.y, acci[s], 0, 0, 0);
-                    acci[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, bf.x, acci[s], 0, 0, 0);
+                    s1[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, bf.x, s1[s], 0, 0, 0);
+                    s2[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, bf.y, s2[s], 0, 0, 0);
+                    s3[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x + af.y, bf.x + bf.y, s3[s], 0, 0, 0);
                 }
             }
         }
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = row0 + ti * 16 + fk + 4 * r, gj = col0 + tj * 16 + fi;
-                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(accr[s][r], acci[s][r]);
+                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
             }
         }
     }
