@@ -38,12 +38,18 @@ namespace {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
-constexpr int RS_NB = 16;                // panel width of the small inverse = one column tile
+#ifndef RS_PANEL
+#define RS_PANEL 8
+#endif
+constexpr int RS_NB = RS_PANEL;           // panel width of the small inverse: half a column tile (8) or a whole one (16)
 #ifndef RS_PRIO
 #define RS_PRIO 1
 #endif
 #ifndef RS_REMAINDER
 #define RS_REMAINDER 1
+#endif
+#ifndef RS_ROW_MODE
+#define RS_ROW_MODE 0                 // pivot row of the factoring wave: 0 LDS line (round 2), 1 v_readlane, 2 ds_bpermute
 #endif
 
 struct ChainRsArgs {
@@ -168,7 +174,7 @@ __device__ __forceinline__ double rs_readlane_f64(double v, int srclane)
 // the end of the panel: the later steps act linearly on it, and every lane runs the same select-free update.
 template <int P>
 __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colof, cplx* rowline /*[16] LDS*/,
-                                          int p0, int pw, int lane)
+                                          int p0, int pw, int lane, unsigned long long* fst = nullptr /* diagnostic: cycle stamps of column step 4 */)
 {
     const int r = rs_opaque(lane);                      // (see rs_opaque: nothing derived from the lane index is
     cplx a[RS_NB];                                      //  hoisted out of the fixed-point loop and kept alive)
@@ -184,6 +190,9 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
 #pragma unroll
     for (int j = 0; j < RS_NB; ++j) {
         if (j < pw) {
+            const bool stamp_here = fst && j == 4;
+            unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0;
+            if (stamp_here) tq0 = __builtin_amdgcn_s_memtime();
             const double v = cabs1(a[j]);
             const unsigned hi = (avail && v == v) ? (unsigned)__double2hiint(v) : 0u;
             const unsigned m = rs_wave_max_u32(hi);
@@ -195,11 +204,13 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
                 pphys = av ? (int)__ffsll(av) - 1 : 0x7fffffff;
             }
             pphys = __builtin_amdgcn_readfirstlane(pphys);
+            if (stamp_here) tq1 = __builtin_amdgcn_s_memtime();
             const bool is_piv = r == pphys;
             cplx rb[RS_NB];
-            // one lane writes, all lanes read: the wave-level barriers keep the compiler from ordering the
-            // two sides of the divergent branch the other way round (it does, without them), the LDS then
-            // executes the wave's instructions in order
+#if RS_ROW_MODE == 0
+            // through a 256-byte LDS line: one lane writes its 16 values, all lanes read them back.  The wave-level
+            // barriers keep the compiler from ordering the two sides of the divergent branch the other way round
+            // (it does, without them), the LDS then executes the wave's instructions in order
             __builtin_amdgcn_wave_barrier();            // the reads of the previous column step are issued
             if (is_piv) {
                 pivrow[p0 + j] = pphys; colof[pphys] = p0 + j;
@@ -211,6 +222,26 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int s = 0; s < RS_NB; ++s) rb[s] = rowline[s];
+#elif RS_ROW_MODE == 1
+            // through v_readlane (wave-uniform results, scalar operands of the FMAs): measured 10 cycles each
+            if (is_piv) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
+#pragma unroll
+            for (int s = 0; s < RS_NB; ++s)
+                rb[s] = cmake(rs_readlane_f64(a[s].x, pphys), rs_readlane_f64(a[s].y, pphys));
+#else
+            // through ds_bpermute_b32: every lane reads the pivot lane's register over the LDS crossbar -- no memory,
+            // no write -> wait -> read round trip, no wave barriers: one pass of 64 pipelined LDS instructions
+            if (is_piv) { pivrow[p0 + j] = pphys; colof[pphys] = p0 + j; }
+            const int baddr = pphys << 2;
+#pragma unroll
+            for (int s = 0; s < RS_NB; ++s) {
+                rb[s].x = __hiloint2double(__builtin_amdgcn_ds_bpermute(baddr, __double2hiint(a[s].x)),
+                                           __builtin_amdgcn_ds_bpermute(baddr, __double2loint(a[s].x)));
+                rb[s].y = __hiloint2double(__builtin_amdgcn_ds_bpermute(baddr, __double2hiint(a[s].y)),
+                                           __builtin_amdgcn_ds_bpermute(baddr, __double2loint(a[s].y)));
+            }
+#endif
+            if (stamp_here) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq2 = __builtin_amdgcn_s_memtime(); }
             const cplx pv = rb[j];
             const double d = pv.x * pv.x + pv.y * pv.y;
             double sc = __builtin_amdgcn_rcp(d);
@@ -219,8 +250,15 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
             const cplx ip = cmake(pv.x * sc, -pv.y * sc);
             const cplx mf = cneg(cmul(a[j], ip));
             const cplx coef = cmake(is_piv ? 0.0 : mf.x, is_piv ? 0.0 : mf.y);
+            if (stamp_here) { asm volatile("" :: "v"(coef.x), "v"(coef.y)); tq3 = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
             for (int s = 0; s < RS_NB; ++s) a[s] = cfma(a[s], coef, rb[s]);
+            if (stamp_here) {
+#pragma unroll
+                for (int s = 0; s < RS_NB; ++s) asm volatile("" :: "v"(a[s].x), "v"(a[s].y));
+                tq4 = __builtin_amdgcn_s_memtime();
+                if (lane == 0) { fst[0] = tq0; fst[1] = tq1; fst[2] = tq2; fst[3] = tq3; fst[4] = tq4; }
+            }
             a[j] = is_piv ? cmake(1.0, 0.0) : coef;
             myip = cmake(is_piv ? ip.x : myip.x, is_piv ? ip.y : myip.y);
             avail = avail && !is_piv;
@@ -254,7 +292,7 @@ __device__ __forceinline__ void rs_load_qf(const cplx* W, const int* pivrow, int
 // one tile (ti, tj): a full 16 x 16 tile, or a row / column strip (one value per lane, corner: one block)
 template <int P, int NKS, int TR>
 __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof, int ti, int tj, int p0, int pw,
-                                               int fi, int fk, const cplx (&qf)[NKS])
+                                               int fi, int fk, const cplx (&qf)[NKS], int clo, int chi /* columns [clo, chi) are stored */)
 {
     const bool rowstrip = TR >= 0 && ti == TR, colstrip = TR >= 0 && tj == TR;
     if (!rowstrip && !colstrip) {
@@ -281,7 +319,8 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + fk + 4 * r;
-            if (i < n && tj * 16 + fi < n) cbase[4 * r * P] = M3 ? cmake(ua[r] - ub[r], uc[r] - ua[r] - ub[r]) : cmake(ua[r], uc[r]);
+            const int cj = tj * 16 + fi;
+            if (i < n && cj < n && cj >= clo && cj < chi) cbase[4 * r * P] = M3 ? cmake(ua[r] - ub[r], uc[r] - ua[r] - ub[r]) : cmake(ua[r], uc[r]);
         }
     } else {
         const int row = rowstrip ? TR * 16 + fk : ti * 16 + 4 * (fi >> 2) + fk;
@@ -299,7 +338,7 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
             mfma3s(ua, ub, uc, pa[ks].x, pa[ks].y, pa[ks].x + pa[ks].y, qf[ks].x, qf[ks].y, qf[ks].x + qf[ks].y);
-        if (mine && row < n && col < n) *cptr = cmake(ua - ub, uc - ua - ub);
+        if (mine && row < n && col < n && col >= clo && col < chi) *cptr = cmake(ua - ub, uc - ua - ub);
     }
 }
 
@@ -307,7 +346,7 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
 // into registers before the first store, so the owner needs no snapshot of the pivot rows.
 template <int T16, int P, int NKS, int TR>
 __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow, const int* colof,
-                                              int tj, int p0, int pw, int lane)
+                                              int tj, int p0, int pw, int lane, int clo, int chi)
 {
     constexpr int FT = TR >= 0 ? TR : T16;                   // full row tiles
     const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
@@ -316,12 +355,13 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
     if (TR >= 0 && tj == TR) {                               // the column strip: every tile on the 4x4x4 instruction
 #pragma unroll
         for (int ti = 0; ti < T16; ++ti) {
-            rs_update_tile<P, NKS, TR>(n, W, colof, ti, tj, p0, pw, fi, fk, qf);
+            rs_update_tile<P, NKS, TR>(n, W, colof, ti, tj, p0, pw, fi, fk, qf, clo, chi);
             __builtin_amdgcn_sched_barrier(0);
         }
         return;
     }
     const int col = tj * 16 + fi;
+    const bool colin = col >= clo && col < chi;             // this lane's column is one of those to be updated
     constexpr bool M3 = P > 35;                              // 3M (mfma3) in the 168-VGPR kernels
     double qs[NKS];                                          // 3M: re + im of the Q fragment, once per column tile
 #pragma unroll
@@ -359,11 +399,11 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + fk + 4 * r;
             // with a remainder strip (TR >= 0) the full tiles lie inside the matrix: rows, columns < 16 TR < n
-            if (TR >= 0 || (i < n && col < n)) cbase[(ti * 16 + 4 * r) * P] = M3 ? cmake(ua[r] - ub[r], uc[r] - ua[r] - ub[r]) : cmake(ua[r], uc[r]);
+            if (colin && (TR >= 0 || (i < n && col < n))) cbase[(ti * 16 + 4 * r) * P] = M3 ? cmake(ua[r] - ub[r], uc[r] - ua[r] - ub[r]) : cmake(ua[r], uc[r]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (TR >= 0) rs_update_tile<P, NKS, TR>(n, W, colof, TR, tj, p0, pw, fi, fk, qf);    // the row strip
+    if (TR >= 0) rs_update_tile<P, NKS, TR>(n, W, colof, TR, tj, p0, pw, fi, fk, qf, clo, chi);    // the row strip
 }
 
 // In-place blocked Gauss-Jordan reduction of the n x n matrix W (LDS, pitch P) with implicit
@@ -380,36 +420,50 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
     int sti = 0;
     auto stamp = [&]() __attribute__((always_inline)) { if (st && tid == 0) st[sti] = __builtin_amdgcn_s_memrealtime(); ++sti; };
     const int npanels = (n + RS_NB - 1) / RS_NB;
+    const int ntiles = (n + 15) >> 4;
     for (int sgi = -1; sgi < npanels; ++sgi) {
         const bool has_cur = sgi >= 0, has_next = sgi + 1 < npanels;
         const int p0 = has_cur ? sgi * RS_NB : 0, pw = has_cur ? min(RS_NB, n - p0) : 0;
         const int n0 = (sgi + 1) * RS_NB, nw = has_next ? min(RS_NB, n - n0) : 0;
+        const int tp = p0 >> 4, tl = n0 >> 4;                   // column tiles of the panel and of the next one
         // the wave that factors panel sgi+1: the chain wave (role RS_WAVES-1), or -- roles by wave number -- each in turn
         const int fw = fixed_fw ? RS_WAVES - 1 : (sgi + 1) & (RS_WAVES - 1);
         if (has_cur && has_next) {
-            // the look-ahead column tile, one row tile per wave (T16 <= 4 = number of waves)
+            // look-ahead: the columns of panel sgi+1 (a whole column tile, or one half of one), one row tile per wave
+            // (T16 <= 4 = number of waves)
             const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
             cplx qf[RS_NB / 4];
-            rs_load_qf<P, RS_NB / 4, TR>(W, pivrow, sgi + 1, p0, pw, fi, fk, qf);
+            rs_load_qf<P, RS_NB / 4, TR>(W, pivrow, tl, p0, pw, fi, fk, qf);
             __syncthreads();
-            if (wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, sgi + 1, p0, pw, fi, fk, qf);
+            if (wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, tl, p0, pw, fi, fk, qf, n0, n0 + RS_NB);
             __syncthreads();
         }
         if (has_cur) {
-            // the other column tiles, one owner each (the owner reads its Q fragment before it writes): dealt
-            // to the three waves that do not factor, to all four after the last panel
+            // the other columns, tile by tile, one owner per tile (the owner reads its Q fragment before it writes):
+            // dealt to the three waves that do not factor, to all four after the last panel.  A tile's columns minus
+            // the panel's own and minus the look-ahead columns (panels of 8: one half of the panel's tile remains when
+            // the panel is its upper half, one half of the next tile when the look-ahead took its lower half).
             const int team = has_next ? RS_WAVES - 1 : RS_WAVES;
             const int me = has_next ? ((wave - fw - 1) & (RS_WAVES - 1)) : wave;
             int cnt = 0;
 #pragma unroll 1
-            for (int tj = 0; tj < npanels; ++tj) {
-                if (tj == sgi || (has_next && tj == sgi + 1)) continue;
+            for (int tj = 0; tj < ntiles; ++tj) {
+                int clo = tj * 16, chi = tj * 16 + 16;
+                if (tj == tp) {
+                    if (RS_NB == 16) continue;
+                    if (p0 & 8) chi = p0; else clo = p0 + RS_NB;
+                }
+                if (has_next && tj == tl) {
+                    if (RS_NB == 16) continue;
+                    if (n0 & 8) chi = min(chi, n0); else clo = max(clo, n0 + RS_NB);
+                }
+                if (clo >= chi || clo >= n) continue;
                 const bool mine = (!has_next || wave != fw) && (cnt % team == me);
                 ++cnt;
                 if (mine) {
-                    // a narrow last panel (<= 4 columns) runs one k-step instead of four
-                    if (pw <= 4) rs_update_col<T16, P, 1, TR>(n, W, pivrow, colof, tj, p0, pw, lane);
-                    else rs_update_col<T16, P, RS_NB / 4, TR>(n, W, pivrow, colof, tj, p0, pw, lane);
+                    // a narrow last panel (<= 4 columns) runs one k-step
+                    if (pw <= 4) rs_update_col<T16, P, 1, TR>(n, W, pivrow, colof, tj, p0, pw, lane, clo, chi);
+                    else rs_update_col<T16, P, RS_NB / 4, TR>(n, W, pivrow, colof, tj, p0, pw, lane, clo, chi);
                 }
             }
         }
@@ -418,7 +472,7 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
             // the factoring wave is its workgroup's critical path (the others wait for it at the barrier):
             // it goes first when it shares its SIMD's issue slots with waves of the other workgroups
             if (RS_PRIO) __builtin_amdgcn_s_setprio(3);
-            rs_factor<P>(n, W, pivrow, colof, rowline, n0, nw, lane);
+            rs_factor<P>(n, W, pivrow, colof, rowline, n0, nw, lane, (st && sgi + 1 == 1) ? st + 40 : nullptr);
             if (RS_PRIO) __builtin_amdgcn_s_setprio(0);
             if (st && lane == 0) st[17 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
         }
@@ -903,8 +957,10 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
                     us(1), us(2) - us(1), us(3) - us(2), us(4) - us(3), us(4));
             for (int i = 8; i < 16 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) / 100.0);
             fprintf(stderr, " | mix: lds %.2f vmem %.2f computed+stored %.2f barrier %.2f", us(5) - us(1), us(6) - us(1), us(7) - us(1), us(40) - us(1));
+            fprintf(stderr, " | column step 4 of panel 1 (shader cycles): search %llu  pivot-row exchange %llu  reciprocal+coef %llu  64 FMAs %llu",
+                    h[8 + 41] - h[8 + 40], h[8 + 42] - h[8 + 41], h[8 + 43] - h[8 + 42], h[8 + 44] - h[8 + 43]);
             fprintf(stderr, " | factor begin-end:");
-            for (int i = 24; i < 34 && h[i]; i += 2) fprintf(stderr, " %.2f-%.2f", (double)(h[i] - h[0]) / 100.0, (double)(h[i + 1] - h[0]) / 100.0);
+            for (int i = 24; i < 38 && h[i]; i += 2) fprintf(stderr, " %.2f-%.2f", (double)(h[i] - h[0]) / 100.0, (double)(h[i + 1] - h[0]) / 100.0);
             fprintf(stderr, "\n");
         }
     }
