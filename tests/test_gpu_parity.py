@@ -404,11 +404,14 @@ def test_compact_gamma_products_match_dense_and_oracle(engine):
             assert abs(T[0][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
 
 
-@pytest.mark.parametrize("nc", [4, 10, 18, 20, 33, 48, 50, 51, 64, 65, 80])
+@pytest.mark.parametrize("nc", [4, 8, 9, 10, 16, 17, 18, 20, 24, 25, 33, 35, 40, 41, 48, 49, 50, 51, 56, 57, 63, 64, 65, 80])
 def test_chain1d_fixed_trip_count(engine, nc):
     """Same number of sweeps on both sides -> the iterate itself must agree.  n_c = 33/48 and 50/64
-    are the three- and four-tile kernels (50 = BASELINE C3's lead); 18, 33, 50, 51 run their last tile as a
-    remainder strip on the 4x4x4 matrix instruction; 65 and 80 the global-scratch kernel for n_c > 64."""
+    are the three- and four-tile kernels (50 = BASELINE C3's lead); 17-19, 33-35, 49-51 run their last tile as a
+    remainder strip on the 4x4x4 matrix instruction; 65 and 80 the global-scratch kernel for n_c > 64.  The
+    panels of the small inverse are 8 columns wide (half a column tile): 8, 16, 24, 40, 56 end on a panel boundary,
+    9, 17, 25, 41, 49, 57 start a panel of one column, 63 ends one column short -- every pitch class and both
+    halves of a tile as the last panel."""
     N = 3 * nc
     F, S, g_dev, g_ref = _chain_system(N, nc, 70 + nc, 1e-4)
     g_dev.force_iters = 40; g_ref.force_iters = 40
