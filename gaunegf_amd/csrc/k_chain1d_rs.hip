@@ -571,7 +571,10 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // (52-64 VGPRs that the three-workgroups-per-CU budget does not have): each product streams it from the
     // lead matrices, which every workgroup of the contact shares (L2 / L1 resident), PF k-steps ahead.
     // Rows >= n give garbage in output rows / columns >= n only (never stored); k >= n is zeroed.
-    constexpr int PF = 3;
+#ifndef RS_PF
+#define RS_PF 1
+#endif
+    constexpr int PF = RS_PF;                       // k-steps the streamed operand is requested ahead
     const cplx* opS = Sbeta; const cplx* opM = beta; cplx opz = z;
     struct Stream { cplx s[PF], m[PF]; };
     auto stream_fetch = [&](Stream& q, const cplx* sS, const cplx* sM, int ks, int fk) __attribute__((always_inline)) {
@@ -596,16 +599,23 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         for (int ks = 0; ks < PF; ++ks) stream_fetch(q, sS, sM, ks, fk);
 #pragma unroll
         for (int tj = 0; tj < T16; ++tj) { accr[tj] = (d4){0, 0, 0, 0}; acci[tj] = (d4){0, 0, 0, 0}; accc[tj] = (d4){0, 0, 0, 0}; }
+        // the LDS operands (B fragments of the work matrix) of k-step ks+1 are requested in front of the matrix
+        // instructions of k-step ks: an LDS round trip is ~300 cycles on a CU whose LDS three workgroups share
+        cplx qbuf[2][T16];
+        auto load_qb = [&](int ks, cplx (&qb)[T16]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int tj = 0; tj < FT; ++tj) qb[tj] = bb[ks * 4 * P + tj * 16];
+            if (REM) qb[TR] = strip_wave ? bb[ks * 4 * P + TR * 16] : bb4[ks * 4 * P + TR * 16];
+        };
+        load_qb(0, qbuf[0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
                 const cplx pa = stream_elem(q, ks, fk);
                 const double ps = pa.x + pa.y;
                 if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
-                cplx qb[T16];
-#pragma unroll
-                for (int tj = 0; tj < FT; ++tj) qb[tj] = bb[ks * 4 * P + tj * 16];
-                if (REM) qb[TR] = strip_wave ? bb[ks * 4 * P + TR * 16] : bb4[ks * 4 * P + TR * 16];
+                cplx (&qb)[T16] = qbuf[ks & 1];
+                if (ks + 1 < KS && ks + 1 < ksteps) load_qb(ks + 1, qbuf[(ks + 1) & 1]);
                 if (strip_wave) {
 #pragma unroll
                     for (int tj = 0; tj < T16; ++tj) { if (M3G) RS_M3S(accr[tj], acci[tj], accc[tj], pa.x, pa.y, ps, qb[tj].x, qb[tj].y, qb[tj].x + qb[tj].y); else RS_ZMFMA4(accr[tj], acci[tj], pa, qb[tj]); }
@@ -615,9 +625,6 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                     if (REM) { if (M3G) RS_M3S(accr[TR], acci[TR], accc[TR], pa.x, pa.y, ps, qb[TR].x, qb[TR].y, qb[TR].x + qb[TR].y); else RS_ZMFMA4(accr[TR], acci[TR], pa, qb[TR]); }
                 }
             }
-            // the LDS operands of the next k-step are not requested earlier than this: the register file
-            // holds the accumulators and ONE set of streamed operands; the other workgroups of the CU
-            // cover the LDS latency
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -634,16 +641,21 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         for (int ks = 0; ks < PF; ++ks) stream_fetch(q, sS, sM, ks, fk);
 #pragma unroll
         for (int ti = 0; ti < T16; ++ti) { accr[ti] = (d4){0, 0, 0, 0}; acci[ti] = (d4){0, 0, 0, 0}; accc[ti] = (d4){0, 0, 0, 0}; }
+        cplx pbuf[2][T16];                               // A fragments of the work matrix, double buffered (see gemm_rowtile)
+        auto load_pa = [&](int ks, cplx (&pa)[T16]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ti = 0; ti < FT; ++ti) pa[ti] = ab[ti * 16 * P + ks * 4];
+            if (REM) pa[TR] = ab4[TR * 16 * P + ks * 4];
+        };
+        load_pa(0, pbuf[0]);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks < ksteps) {
                 const cplx br = stream_elem(q, ks, fk);
                 const double bd = br.x - br.y;
                 if (ks + PF < KS) stream_fetch(q, sS, sM, ks + PF, fk);
-                cplx pa[T16];
-#pragma unroll
-                for (int ti = 0; ti < FT; ++ti) pa[ti] = ab[ti * 16 * P + ks * 4];
-                if (REM) pa[TR] = ab4[TR * 16 * P + ks * 4];
+                cplx (&pa)[T16] = pbuf[ks & 1];
+                if (ks + 1 < KS && ks + 1 < ksteps) load_pa(ks + 1, pbuf[(ks + 1) & 1]);
                 // pa * conj(b)
                 if (strip_wave) {
 #pragma unroll
