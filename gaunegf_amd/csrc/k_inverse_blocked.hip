@@ -1198,16 +1198,27 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     if (groups == 1) {
         chain(st, 0, nb);
     } else {
-        constexpr int MAXG = 4;
-        static hipStream_t side[MAXG - 1] = {nullptr, nullptr, nullptr};
-        static hipEvent_t ev_fork = nullptr, ev_join[MAXG - 1] = {nullptr, nullptr, nullptr};
-        if (!ev_fork) {
-            (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        constexpr int MAXG = 4, MAXDEV = 16;
+        // side streams and fork / join events of the CURRENT device (a process may drive several contexts on
+        // several devices; streams and events belong to the device they were created on)
+        struct Side { hipStream_t s[MAXG - 1]; hipEvent_t fork, join[MAXG - 1]; bool ok; };
+        static Side per_dev[MAXDEV] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= MAXDEV) { chain(st, 0, nb); return; }
+        Side& sd = per_dev[dev];
+        if (!sd.ok) {
+            bool good = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
             for (int g = 0; g < MAXG - 1; ++g) {
-                (void)hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking);
-                (void)hipEventCreateWithFlags(&ev_join[g], hipEventDisableTiming);
+                good = good && hipStreamCreateWithFlags(&sd.s[g], hipStreamNonBlocking) == hipSuccess;
+                good = good && hipEventCreateWithFlags(&sd.join[g], hipEventDisableTiming) == hipSuccess;
             }
+            if (!good) { (void)hipGetLastError(); chain(st, 0, nb); return; }
+            sd.ok = true;
         }
+        hipStream_t* side = sd.s;
+        hipEvent_t ev_fork = sd.fork;
+        hipEvent_t* ev_join = sd.join;
         (void)hipEventRecord(ev_fork, st);
         const int per = (nb + groups - 1) / groups;
         for (int g = 1; g < groups; ++g) {
