@@ -63,6 +63,7 @@ struct ChainRsArgs {
     int gold_lds_off, gold_lds_slots; // the first slots of a lane's copy live in LDS at this element offset
     const int* order;                // launch slot -> job (energy * n_contacts + contact), longest jobs first; or null
     unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
+    int stamp_sweep;                 // diagnostic: the sweep of job 0 whose phases are stamped (NEGF_CHAIN_STAMP_SWEEP, default 10)
     int simd_roles;                  // 1: wave roles follow the SIMD a wave runs on (see rs_wave_role), 0: the wave number
 };
 
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     int count = 0;
     bool first = true, final_pass = false;
     while (true) {
-        unsigned long long* st = (a.stamps && job == 0 && count == 10) ? a.stamps : nullptr;
+        unsigned long long* st = (a.stamps && job == 0 && count == a.stamp_sweep) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
         rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
         if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
@@ -935,6 +936,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
         if (want_stamps) { (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, 64 * sizeof(unsigned long long)); }
     }
     a.stamps = d_stamps;
+    { const char* e = getenv("NEGF_CHAIN_STAMP_SWEEP"); a.stamp_sweep = e ? atoi(e) : 10; }
     static int occ_env = -1;
     if (occ_env < 0) { const char* e = getenv("NEGF_CHAIN1D_OCC"); occ_env = e ? atoi(e) : 0; }
     static int roles_env = -1;
@@ -965,7 +967,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         if (h[0]) {
             auto us = [&](int i) { return h[i] ? (double)(h[i] - h[0]) / 100.0 : -1.0; };
-            fprintf(stderr, "[chain stamps] sweep 10 (us): inverse %.2f  diff+mix %.2f  T=Bg %.2f  M=A-TB^H %.2f  (total %.2f) | inverse stages:",
+            fprintf(stderr, "[chain stamps] sweep %d (us):", a.stamp_sweep); fprintf(stderr, " inverse %.2f  diff+mix %.2f  T=Bg %.2f  M=A-TB^H %.2f  (total %.2f) | inverse stages:",
                     us(1), us(2) - us(1), us(3) - us(2), us(4) - us(3), us(4));
             for (int i = 8; i < 16 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) / 100.0);
             fprintf(stderr, " | mix: lds %.2f vmem %.2f computed+stored %.2f barrier %.2f", us(5) - us(1), us(6) - us(1), us(7) - us(1), us(40) - us(1));
