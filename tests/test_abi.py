@@ -64,3 +64,31 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_bench_quotes_pmc_traffic_only_from_a_profile_of_the_tree_kernels(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed PMC profile ONLY while the profile records the sha256 of
+    the kernel source it was taken on and that equals the tree's; otherwise null with the reason."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    csrc = tmp_path / "gaunegf_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "k_chain1d_rs.hip").write_text("// kernel v2\n")
+    sha = bench.kernel_source_id()
+    assert sha is not None and len(sha) == 16
+    name = "void chain1d_rs_kernel<51, 3, true>(...)"
+    stale = {name: {"FETCH_SIZE": 10.0, "WRITE_SIZE": 20.0}, "_kernel_source_sha16": {"k_chain1d_rs.hip": "0" * 16}}
+    (prof / "r09_pmc_c3_per_launch_avg.json").write_text(json.dumps(stale))
+    val, why = bench.pmc_traffic_bytes("chain1d_rs_kernel")
+    assert val is None and "another version" in why
+    good = dict(stale, _kernel_source_sha16={"k_chain1d_rs.hip": sha})
+    (prof / "r10_pmc_c3_per_launch_avg.json").write_text(json.dumps(good))
+    val, src = bench.pmc_traffic_bytes("chain1d_rs_kernel")
+    assert val == (2 * 10.0 + 20.0) * 1024.0 and src.endswith("r10_pmc_c3_per_launch_avg.json")
+    # the committed round-3 profile belongs to the committed kernel
+    monkeypatch.undo()
+    val, src = bench.pmc_traffic_bytes("chain1d_rs_kernel")
+    assert val is None or src.startswith("profiles/")
