@@ -187,8 +187,10 @@ def cpu_baseline_pool(kind, payload, E, w, n_sample, label, workers=None):
         t0 = time.perf_counter()
         parts = pool.map(_pool_chunk, chunks, chunksize=1)
         dt = time.perf_counter() - t0
-    assert np.all(np.isfinite(sum(parts)))
-    return {"value": len(idx) / dt, "unit": "energy-points/s", "cores": int(workers), "kind": "port",
+    total = sum(parts)
+    assert np.all(np.isfinite(total))
+    return {"_sum": total, "_idx": idx,
+            "value": len(idx) / dt, "unit": "energy-points/s", "cores": int(workers), "kind": "port",
             "sample": f"{len(idx)} of {E.size} energies (evenly spaced, {100.0 * len(idx) / E.size:.1f} % of the grid) of "
                       f"{label}; numpy {np.__version__} oracle loop (reference CPU restatement) in {workers} processes "
                       f"x 1 BLAS thread ({host_cpus()} usable CPUs of {os.cpu_count()} on the host), {dt:.1f} s"}
@@ -373,6 +375,13 @@ def worker_c3(args):
                                budget_s=min(args.cpu_budget, 8.0))
             # the whole-host figure: >= 5 % of the grid over a pool of single-thread oracle processes
             pool = cpu_baseline_pool("c3", (F, S, inds, kw, ETA), Er, wr, max(M // 20, 64), label)
+            # the same sample through the device path (not timed): the CPU leg doubles as a parity check of the
+            # benchmarked configuration at full size, production stopping rule included
+            cpu_sum, sidx = pool.pop("_sum"), pool.pop("_idx")
+            dev_sum = eng.gr_int(h, E_loc[sidx], w_loc[sidx])
+            pool["parity_rel_fro_device_vs_cpu_on_sample"] = float(np.linalg.norm(dev_sum - cpu_sum) / np.linalg.norm(cpu_sum))
+            # (a converged fixed point may stop one sweep earlier or later than the oracle's: Sigma within 10 conv = 1e-4)
+            assert pool["parity_rel_fro_device_vs_cpu_on_sample"] < 1e-4, pool["parity_rel_fro_device_vs_cpu_on_sample"]
             line["cpu_baseline"] = pool
             line["cpu_baseline"]["one_process"] = {k: one[k] for k in ("value", "cores", "points_per_s_by_blas_threads", "sample")}
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / pool["value"]
