@@ -994,16 +994,18 @@ constexpr int CU_THREADS = 512;
 constexpr int CU_AP = 65;                         // odd pitch of the A tile in LDS: conflict-free fragment reads
 
 __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
-    int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cw)
+    int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cw,
+    int only_blk /* >= 0: this column block of every matrix and no other (window pairs, see gj_colupdate2_kernel) */)
 {
     __shared__ cplx As[2][64 * CU_AP];            // P'[I] of the current and of the next row block
     __shared__ unsigned char pflag[8192];         // row is a pivot row of this window (its old content counts as zero)
-    const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = nblk - 1;
+    const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = only_blk >= 0 ? 1 : nblk - 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int m = (slot / per_mat) * 8 + xcd;
     if (m >= nb) return;                                         // (uniform)
     int jb = slot % per_mat;
-    if (jb >= jwin) ++jb;                                        // skip the window's own block
+    if (only_blk >= 0) jb = only_blk;
+    else if (jb >= jwin) ++jb;                                   // skip the window's own block
     cplx* W = bufA + (size_t)m * mat_stride;
     const int* pivrow = piv_all + (size_t)m * 2 * n;
     const int* colof = pivrow + n;
@@ -1119,6 +1121,209 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
     store_block(nblk - 1);
 }
 
+// ---- Column-block update with a PAIR of windows, A = [c0, c0+64) and B = [c0+64, c0+64+cwB), in ONE pass over the
+// column block: the single-window update above reads and writes every block outside the window once per window
+// (1000 matrices of n = 500: 7 GB per window, as much time in loads and stores as in matrix instructions); with
+// the pair fused the old block is read once, takes both rank-64 updates in the accumulators and is written once.
+//     W' = keepA(W) + P'A QA            QA = rows pivA of W  (block J, in place)
+//     W''= keepB(W') + P'B QB           QB = rows pivB of W' = W[pivB] + P'A[pivB] QA   (pivB rows are no pivA rows)
+// The launch sequence of a pair (gj_large_launch): window kernel A; single-window update of block B alone;
+// window kernel B (its columns are up to date with A); THIS kernel on all blocks but A and B; single-window
+// update with B of block A alone (whose columns -- P'A -- this kernel reads and must find untouched).
+// * QB is formed first: the 64 pivot rows of B as one virtual row block (their P'A rows staged in LDS), the
+//   product on the matrix cores; the FP64 16x16x4 accumulator layout (lane l, register v <-> row 4v + (l>>4),
+//   column l&15) IS the B-operand fragment of k-step v, so the two waves of a column tile only exchange their
+//   halves through LDS and both Q sets then sit in registers (128 VGPRs) for the whole pass;
+// * row blocks of 32 stream through (P'A[I] and P'B[I] by LDS-DMA, double buffered: 4 x 33 KB), one 16 x 16 tile
+//   per wave; between the two rank-64 phases the accumulators of B's pivot rows are cleared -- the sums stay in
+//   3M form (s1, s2, s3) across both phases and are recombined once;
+// * software pipeline and XCD-aware launch order as in gj_colupdate_kernel.
+__global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
+    int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cwB)
+{
+    __shared__ cplx As2[2][2][32 * CU_AP];        // [buffer][window A / B] P'[I], 32 rows
+    __shared__ unsigned char pflag[8192];         // bit 0: pivot row of window A, bit 1: of window B
+    const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = nblk - 2, cB = c0 + 64;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int m = (slot / per_mat) * 8 + xcd;
+    if (m >= nb) return;                                         // (uniform)
+    int jb = slot % per_mat;
+    if (jb >= jwin) jb += 2;                                     // skip the blocks of the two windows
+    cplx* W = bufA + (size_t)m * mat_stride;
+    const int* pivrow = piv_all + (size_t)m * 2 * n;
+    const int* colof = pivrow + n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wh = wave >> 2, wc = (wave & 3) * 16;              // row half / column tile of this wave
+    const int fi = lane & 15, fk = lane >> 4;
+    const int col = jb * 64 + wc + fi;
+    const bool col_ok = col < n;
+    const int colc = col_ok ? col : n - 1;
+
+    for (int i = tid; i < n; i += CU_THREADS) {
+        const int c = colof[i];
+        pflag[i] = (unsigned char)(((c >= c0 && c < cB) ? 1 : 0) | ((c >= cB && c < cB + cwB) ? 2 : 0));
+    }
+    auto lds_dma_row = [&](const cplx* src, cplx* dst) __attribute__((always_inline)) {
+        const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);     // wave-uniform -> SGPR
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+    };
+    // ---- QA in place; QB = W[pivB] + P'A[pivB] QA
+    cplx qfA[16], qfB[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const cplx v = W[(size_t)pivrow[c0 + ks * 4 + fk] * n + colc];
+        qfA[ks] = cmake(col_ok ? v.x : 0.0, col_ok ? v.y : 0.0);
+    }
+    {
+        cplx* R0 = &As2[0][0][0];                  // [64][CU_AP]: P'A of B's pivot rows
+        cplx* Xs = &As2[1][0][0];                  // [4 column tiles][16 k-steps][64 lanes]: QB fragments
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = wave * 8 + j;
+            lds_dma_row(W + (size_t)pivrow[cB + min(k, cwB - 1)] * n + c0 + lane, R0 + k * CU_AP);
+        }
+        cplx cq[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = wh * 32 + a * 16 + fk + 4 * r;
+                cq[a][r] = W[(size_t)pivrow[cB + min(k, cwB - 1)] * n + colc];
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        d4 cr[2], ci[2], cs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cr[a][r] = cq[a][r].x; ci[a][r] = cq[a][r].x + cq[a][r].y; }
+        const cplx* ab = R0 + (wh * 32 + fi) * CU_AP + fk;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double qs = qfA[ks].x + qfA[ks].y;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const cplx af = ab[a * 16 * CU_AP + ks * 4];
+                cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, qfA[ks].x, cr[a], 0, 0, 0);
+                cs[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, qfA[ks].y, cs[a], 0, 0, 0);
+                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x + af.y, qs, ci[a], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = wh * 32 + a * 16 + fk + 4 * r;
+                const bool ok = (k < cwB) & col_ok;
+                const double re = cr[a][r] - cs[a][r], im = ci[a][r] - cr[a][r] - cs[a][r];
+                Xs[((wave & 3) * 16 + wh * 8 + a * 4 + r) * 64 + lane] = cmake(ok ? re : 0.0, ok ? im : 0.0);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) qfB[ks] = Xs[((wave & 3) * 16 + ks) * 64 + lane];
+        __syncthreads();                           // both staging areas are free for the pipeline's buffers
+    }
+
+    // Addresses of the pipeline are 32-bit byte offsets from the (wave-uniform) matrix base, recomputed where they
+    // are used: with both Q sets in registers (128 VGPRs) there is no room for loop-carried 64-bit pointers
+    // (n <= 8192: 16 n^2 < 2^32).
+    const int nrb = (n + 31) >> 5;
+    const int wr = wh * 16;
+    const char* Wb = reinterpret_cast<const char*>(W);
+    char* Wbw = reinterpret_cast<char*>(W);
+    const unsigned un = (unsigned)n;
+    const unsigned a_lane = (unsigned)(c0 + lane), b_lane = (unsigned)(cB + min(lane, cwB - 1));
+    auto lds_dma_off = [&](unsigned byte_off, cplx* dst) __attribute__((always_inline)) {
+        const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(byte_off), "s"(lds_dst), "s"(Wb) : "memory");
+    };
+    auto fetch_a = [&](int ib, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wave * 4 + j;
+            const unsigned rbase = (unsigned)min(ib * 32 + row, n - 1) * un;
+            lds_dma_off((rbase + a_lane) * 16u, &As2[buf][0][row * CU_AP]);
+            lds_dma_off((rbase + b_lane) * 16u, &As2[buf][1][row * CU_AP]);
+        }
+    };
+    cplx cv[4];
+    auto fetch_c = [&](int ib) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned off = ((unsigned)min(ib * 32 + wr + fk + 4 * r, n - 1) * un + (unsigned)colc) * 16u;
+            cv[r] = *reinterpret_cast<const cplx*>(Wb + off);
+        }
+    };
+    fetch_a(0, 0);
+    fetch_c(0);
+    d4 sr, si;                             // results of the previous row block, not stored yet
+    auto store_block = [&](int ib) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = ib * 32 + wr + fk + 4 * r;
+            const unsigned off = ((unsigned)gi * un + (unsigned)col) * 16u;
+            if (gi < n && col_ok) *reinterpret_cast<cplx*>(Wbw + off) = cmake(sr[r], si[r]);
+        }
+    };
+#pragma unroll 1
+    for (int ib = 0; ib < nrb; ++ib) {
+        const int buf = ib & 1;
+        d4 cr, ci, cs = {0, 0, 0, 0};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of P'[ib] (not in hipcc's bookkeeping)
+        __syncthreads();
+        unsigned fl = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned f = pflag[min(ib * 32 + wr + fk + 4 * r, n - 1)];
+            fl |= f << (2 * r);
+            const bool z = (f & 1u) != 0;
+            cr[r] = z ? 0.0 : cv[r].x; ci[r] = z ? 0.0 : cv[r].x + cv[r].y;
+        }
+        const cplx* abA = &As2[buf][0][(wr + fi) * CU_AP + fk];
+        const cplx* abB = &As2[buf][1][(wr + fi) * CU_AP + fk];
+        cplx af[2];
+        af[0] = abA[0];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int cur = ks & 1;
+            if (ks == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (ib + 1 < nrb) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
+                if (ib > 0) store_block(ib - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            af[cur ^ 1] = ks + 1 < 16 ? abA[(ks + 1) * 4] : abB[0];
+            const double qs = qfA[ks].x + qfA[ks].y;
+            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x, qfA[ks].x, cr, 0, 0, 0);
+            cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].y, qfA[ks].y, cs, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x + af[cur].y, qs, ci, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool z = ((fl >> (2 * r)) & 2u) != 0;   // pivot row of B: its A-updated content was taken into QB
+            cr[r] = z ? 0.0 : cr[r]; cs[r] = z ? 0.0 : cs[r]; ci[r] = z ? 0.0 : ci[r];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int cur = ks & 1;
+            if (ks + 1 < 16) af[cur ^ 1] = abB[(ks + 1) * 4];
+            const double qs = qfB[ks].x + qfB[ks].y;
+            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x, qfB[ks].x, cr, 0, 0, 0);
+            cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].y, qfB[ks].y, cs, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x + af[cur].y, qs, ci, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sr[r] = cr[r] - cs[r]; si[r] = ci[r] - cr[r] - cs[r]; }
+    }
+    store_block(nrb - 1);
+}
+
 __global__ __launch_bounds__(256) void gj_gather_kernel(int n, const cplx* __restrict__ bufA,
                                                          cplx* __restrict__ bufB, size_t mat_stride,
                                                          const int* __restrict__ piv_all,
@@ -1165,6 +1370,8 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     }
     static int winla = -1;
     if (winla < 0) { const char* e = getenv("NEGF_GJ_WINLA"); winla = e ? atoi(e) : 1; }
+    static int pair = -1;                // windows in pairs (one pass over the other column blocks per pair); 0: one by one
+    if (pair < 0) { const char* e = getenv("NEGF_GJ_PAIR"); pair = e ? atoi(e) : 1; }
     const int nblk = (n + 63) / 64;
     // the chain of one group of matrices: per window the panel kernel (one workgroup per matrix: a latency chain
     // that covers at most `count` CUs) and the column-block update (throughput-bound), then the gather
@@ -1172,16 +1379,35 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         cplx* Ag = A + (size_t)first * stride; cplx* Bg = B + (size_t)first * stride;
         int* pg = piv + (size_t)first * 2 * n; int* ig = info + first;
         hipLaunchKernelGGL(gj_state_init_kernel, dim3(count), dim3(256), 0, s, n, pg, ig);
-        for (int c0 = 0; c0 < n; c0 += WIN) {
-            const int cw = min(WIN, n - c0);
+        auto window = [&](int c0, int cw) {
             unsigned long long* stp = (c0 == WIN && first == 0) ? d_stamps : (unsigned long long*)nullptr;
             if (NBI == 16 && RPT == 1 && winla)
                 hipLaunchKernelGGL(gj_window_la_kernel<16>, dim3(count), dim3(LA_THREADS), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
             else
                 hipLaunchKernelGGL(kern, dim3(count), dim3(PT), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
-            if (nblk > 1)
-                hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 1)), dim3(CU_THREADS), 0, s,
-                                   n, count, Ag, stride, (const int*)pg, c0, cw);
+        };
+        auto colupdate = [&](int c0, int cw, int only_blk) {
+            const int blocks = only_blk >= 0 ? 1 : nblk - 1;
+            hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((count + 7) / 8) * blocks), dim3(CU_THREADS), 0, s,
+                               n, count, Ag, stride, (const int*)pg, c0, cw, only_blk);
+        };
+        for (int c0 = 0; c0 < n; c0 += WIN) {
+            const int cw = min(WIN, n - c0);
+            if (pair && nblk >= 3 && c0 + WIN < n) {
+                // windows A = [c0, c0 + 64) and B = the next one as a pair: every block outside the two is read and
+                // written once for both (gj_colupdate2_kernel)
+                const int cB = c0 + WIN, cwB = min(WIN, n - cB), jA = c0 / WIN;
+                window(c0, cw);
+                colupdate(c0, cw, jA + 1);                        // A -> block B
+                window(cB, cwB);
+                hipLaunchKernelGGL(gj_colupdate2_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 2)), dim3(CU_THREADS), 0, s,
+                                   n, count, Ag, stride, (const int*)pg, c0, cwB);
+                colupdate(cB, cwB, jA);                           // B -> block A (P'A is no longer needed)
+                c0 += WIN;
+                continue;
+            }
+            window(c0, cw);
+            if (nblk > 1) colupdate(c0, cw, -1);
         }
         hipLaunchKernelGGL(gj_gather_kernel, dim3(n, count), dim3(256), 0, s, n, (const cplx*)Ag, Bg, stride,
                            (const int*)pg, (const int*)ig);
