@@ -1130,18 +1130,24 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
 // The launch sequence of a pair (gj_large_launch): window kernel A; single-window update of block B alone;
 // window kernel B (its columns are up to date with A); THIS kernel on all blocks but A and B; single-window
 // update with B of block A alone (whose columns -- P'A -- this kernel reads and must find untouched).
+// * TWO lean workgroups per CU (4 waves each, one column tile per wave): the two run their barriers and operand
+//   waits independently of each other (one 8-wave workgroup per CU with row blocks of 32: N = 500 x 1000 26.8 ms
+//   against 25.7, N = 1000 167 against 154);
 // * QB is formed first: the 64 pivot rows of B as one virtual row block (their P'A rows staged in LDS), the
 //   product on the matrix cores; the FP64 16x16x4 accumulator layout (lane l, register v <-> row 4v + (l>>4),
-//   column l&15) IS the B-operand fragment of k-step v, so the two waves of a column tile only exchange their
-//   halves through LDS and both Q sets then sit in registers (128 VGPRs) for the whole pass;
-// * row blocks of 32 stream through (P'A[I] and P'B[I] by LDS-DMA, double buffered: 4 x 33 KB), one 16 x 16 tile
-//   per wave; between the two rank-64 phases the accumulators of B's pivot rows are cleared -- the sums stay in
-//   3M form (s1, s2, s3) across both phases and are recombined once;
+//   column l&15) IS the B-operand fragment of k-step v, so each wave forms the QB of its own column tile in the
+//   registers that hold it for the whole pass (both Q sets: 128 VGPRs);
+// * row blocks of 16 stream through (P'A[I] and P'B[I] by LDS-DMA, double buffered: 4 x 16.6 KB), one 16 x 16
+//   tile per wave; between the two rank-64 phases the accumulators of B's pivot rows are cleared -- the sums stay
+//   in 3M form (s1, s2, s3) across both phases and are recombined once;
+// * addresses are 32-bit byte offsets from the wave-uniform matrix base, recomputed where they are used: with
+//   both Q sets in registers there is no room for loop-carried 64-bit pointers (n <= 8192: 16 n^2 < 2^32);
 // * software pipeline and XCD-aware launch order as in gj_colupdate_kernel.
-__global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
+constexpr int CU4_THREADS = 256;
+__global__ __launch_bounds__(CU4_THREADS, 2) void gj_colupdate2_kernel(
     int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cwB)
 {
-    __shared__ cplx As2[2][2][32 * CU_AP];        // [buffer][window A / B] P'[I], 32 rows
+    __shared__ cplx As2[2][2][16 * CU_AP];        // [buffer][window A / B] P'[I], 16 rows  (66.5 KB)
     __shared__ unsigned char pflag[8192];         // bit 0: pivot row of window A, bit 1: of window B
     const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = nblk - 2, cB = c0 + 64;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1153,24 +1159,31 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
     const int* pivrow = piv_all + (size_t)m * 2 * n;
     const int* colof = pivrow + n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wh = wave >> 2, wc = (wave & 3) * 16;              // row half / column tile of this wave
+    const int wc = wave * 16;                                    // column tile of this wave
     const int fi = lane & 15, fk = lane >> 4;
     const int col = jb * 64 + wc + fi;
     const bool col_ok = col < n;
     const int colc = col_ok ? col : n - 1;
+    // (the matrix base as an explicitly wave-uniform value: scalar base + 32-bit lane offsets in every access)
+    const unsigned long long wbits = (unsigned long long)(size_t)W;
+    const char* Wb = reinterpret_cast<const char*>((size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wbits >> 32)) << 32) |
+                                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(wbits & 0xffffffffu))));
+    char* Wbw = const_cast<char*>(Wb);
+    const unsigned un = (unsigned)n;
+    const unsigned a_lane = (unsigned)(c0 + lane), b_lane = (unsigned)(cB + min(lane, cwB - 1));
 
-    for (int i = tid; i < n; i += CU_THREADS) {
+    for (int i = tid; i < n; i += CU4_THREADS) {
         const int c = colof[i];
         pflag[i] = (unsigned char)(((c >= c0 && c < cB) ? 1 : 0) | ((c >= cB && c < cB + cwB) ? 2 : 0));
     }
-    auto lds_dma_row = [&](const cplx* src, cplx* dst) __attribute__((always_inline)) {
+    auto lds_dma_off = [&](unsigned byte_off, cplx* dst) __attribute__((always_inline)) {
         const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);     // wave-uniform -> SGPR
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(byte_off), "s"(lds_dst), "s"(Wb) : "memory");
     };
-    // ---- QA in place; QB = W[pivB] + P'A[pivB] QA
+    // ---- QA in place; QB = W[pivB] + P'A[pivB] QA (all 64 rows of this wave's column tile)
     cplx qfA[16], qfB[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
@@ -1179,75 +1192,44 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
     }
     {
         cplx* R0 = &As2[0][0][0];                  // [64][CU_AP]: P'A of B's pivot rows
-        cplx* Xs = &As2[1][0][0];                  // [4 column tiles][16 k-steps][64 lanes]: QB fragments
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = wave * 8 + j;
-            lds_dma_row(W + (size_t)pivrow[cB + min(k, cwB - 1)] * n + c0 + lane, R0 + k * CU_AP);
+        for (int j = 0; j < 16; ++j) {
+            const int k = wave * 16 + j;
+            lds_dma_off(((unsigned)pivrow[cB + min(k, cwB - 1)] * un + a_lane) * 16u, R0 + k * CU_AP);
         }
-        cplx cq[2][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = wh * 32 + a * 16 + fk + 4 * r;
-                cq[a][r] = W[(size_t)pivrow[cB + min(k, cwB - 1)] * n + colc];
-            }
+        for (int ks = 0; ks < 16; ++ks)             // qfB starts as the old content of B's pivot rows
+            qfB[ks] = W[(size_t)pivrow[cB + min(ks * 4 + fk, cwB - 1)] * n + colc];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        d4 cr[2], ci[2], cs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        const cplx* ab = R0 + fi * CU_AP + fk;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a) {               // virtual row tile a: k rows 16 a .. 16 a + 15 = k-steps 4 a .. 4 a + 3
+            d4 cr, ci, cs = {0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { cr[a][r] = cq[a][r].x; ci[a][r] = cq[a][r].x + cq[a][r].y; }
-        const cplx* ab = R0 + (wh * 32 + fi) * CU_AP + fk;
+            for (int r = 0; r < 4; ++r) { cr[r] = qfB[a * 4 + r].x; ci[r] = qfB[a * 4 + r].x + qfB[a * 4 + r].y; }
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const double qs = qfA[ks].x + qfA[ks].y;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int ks = 0; ks < 16; ++ks) {
                 const cplx af = ab[a * 16 * CU_AP + ks * 4];
-                cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, qfA[ks].x, cr[a], 0, 0, 0);
-                cs[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, qfA[ks].y, cs[a], 0, 0, 0);
-                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x + af.y, qs, ci[a], 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, qfA[ks].x, cr, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, qfA[ks].y, cs, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x + af.y, qfA[ks].x + qfA[ks].y, ci, 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = wh * 32 + a * 16 + fk + 4 * r;
-                const bool ok = (k < cwB) & col_ok;
-                const double re = cr[a][r] - cs[a][r], im = ci[a][r] - cr[a][r] - cs[a][r];
-                Xs[((wave & 3) * 16 + wh * 8 + a * 4 + r) * 64 + lane] = cmake(ok ? re : 0.0, ok ? im : 0.0);
+                const bool ok = (a * 16 + 4 * r + fk < cwB) & col_ok;
+                qfB[a * 4 + r] = cmake(ok ? cr[r] - cs[r] : 0.0, ok ? ci[r] - cr[r] - cs[r] : 0.0);
             }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) qfB[ks] = Xs[((wave & 3) * 16 + ks) * 64 + lane];
-        __syncthreads();                           // both staging areas are free for the pipeline's buffers
+        }
+        __syncthreads();                           // the staging area is free for the pipeline's buffers
     }
 
-    // Addresses of the pipeline are 32-bit byte offsets from the (wave-uniform) matrix base, recomputed where they
-    // are used: with both Q sets in registers (128 VGPRs) there is no room for loop-carried 64-bit pointers
-    // (n <= 8192: 16 n^2 < 2^32).
-    const int nrb = (n + 31) >> 5;
-    const int wr = wh * 16;
-    const char* Wb = reinterpret_cast<const char*>(W);
-    char* Wbw = reinterpret_cast<char*>(W);
-    const unsigned un = (unsigned)n;
-    const unsigned a_lane = (unsigned)(c0 + lane), b_lane = (unsigned)(cB + min(lane, cwB - 1));
-    auto lds_dma_off = [&](unsigned byte_off, cplx* dst) __attribute__((always_inline)) {
-        const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
-            (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(byte_off), "s"(lds_dst), "s"(Wb) : "memory");
-    };
+    const int nrb = (n + 15) >> 4;
     auto fetch_a = [&](int ib, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = wave * 4 + j;
-            const unsigned rbase = (unsigned)min(ib * 32 + row, n - 1) * un;
+            const unsigned rbase = (unsigned)min(ib * 16 + row, n - 1) * un;
             lds_dma_off((rbase + a_lane) * 16u, &As2[buf][0][row * CU_AP]);
             lds_dma_off((rbase + b_lane) * 16u, &As2[buf][1][row * CU_AP]);
         }
@@ -1256,7 +1238,7 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
     auto fetch_c = [&](int ib) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned off = ((unsigned)min(ib * 32 + wr + fk + 4 * r, n - 1) * un + (unsigned)colc) * 16u;
+            const unsigned off = ((unsigned)min(ib * 16 + fk + 4 * r, n - 1) * un + (unsigned)colc) * 16u;
             cv[r] = *reinterpret_cast<const cplx*>(Wb + off);
         }
     };
@@ -1266,7 +1248,7 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
     auto store_block = [&](int ib) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gi = ib * 32 + wr + fk + 4 * r;
+            const int gi = ib * 16 + fk + 4 * r;
             const unsigned off = ((unsigned)gi * un + (unsigned)col) * 16u;
             if (gi < n && col_ok) *reinterpret_cast<cplx*>(Wbw + off) = cmake(sr[r], si[r]);
         }
@@ -1280,13 +1262,13 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate2_kernel(
         unsigned fl = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned f = pflag[min(ib * 32 + wr + fk + 4 * r, n - 1)];
+            const unsigned f = pflag[min(ib * 16 + fk + 4 * r, n - 1)];
             fl |= f << (2 * r);
             const bool z = (f & 1u) != 0;
             cr[r] = z ? 0.0 : cv[r].x; ci[r] = z ? 0.0 : cv[r].x + cv[r].y;
         }
-        const cplx* abA = &As2[buf][0][(wr + fi) * CU_AP + fk];
-        const cplx* abB = &As2[buf][1][(wr + fi) * CU_AP + fk];
+        const cplx* abA = &As2[buf][0][fi * CU_AP + fk];
+        const cplx* abB = &As2[buf][1][fi * CU_AP + fk];
         cplx af[2];
         af[0] = abA[0];
 #pragma unroll
@@ -1400,7 +1382,7 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
                 window(c0, cw);
                 colupdate(c0, cw, jA + 1);                        // A -> block B
                 window(cB, cwB);
-                hipLaunchKernelGGL(gj_colupdate2_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 2)), dim3(CU_THREADS), 0, s,
+                hipLaunchKernelGGL(gj_colupdate2_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 2)), dim3(CU4_THREADS), 0, s,
                                    n, count, Ag, stride, (const int*)pg, c0, cwB);
                 colupdate(cB, cwB, jA);                           // B -> block A (P'A is no longer needed)
                 c0 += WIN;
