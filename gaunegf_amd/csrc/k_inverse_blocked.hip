@@ -975,29 +975,29 @@ __global__ __launch_bounds__(LA_THREADS) void gj_window_la_kernel(
     if (tid == 0 && bad_sh != 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad_sh;
 }
 
-// ---- Column-block big update.  One workgroup (512 threads, 8 waves, one per CU) OWNS a block of 64 columns
-// outside the window and applies the window to all of its rows:
+// ---- Column-block big update.  A workgroup (256 threads, 4 waves; TWO per CU, which run their barriers and
+// operand waits independently of each other) OWNS a block of 64 columns outside the window and applies the window
+// to all of its rows:
 //     W[i][J] = (row i pivot of the window ? 0 : W[i][J]) + P'[i][0:cw) * Q[0:cw)[J]
 // * Q[:, J] -- the window's pivot rows in the block's columns -- is read IN PLACE into registers before the
 //   first store (16 x n_k fragments of the wave's column tile, 64 VGPRs): only this workgroup ever touches
 //   column block J, so the window kernel needs no Q snapshot (0.5 MB written and read back per matrix and
 //   window at n = 500) and the matrix-core loop has no B-operand traffic at all;
-// * the row blocks of 64 stream through: P'[I] (64 x cw) -> LDS (A operand), the old block C[I][J] -> the
-//   accumulators; the operands of row block I+1 are requested before row block I runs its 128 MFMAs per
-//   wave, so the L2 / HBM latency of the operands and of the old block is covered by matrix work (the
-//   64 x 64-tile-per-workgroup kernel this replaces paid it twice per tile: 22 -> 19.7 ms per 1000 matrices
-//   of n = 500 including the dropped snapshot; measured alone on MI355X: MFMA work 2.06 ms, loads + stores
-//   1.56 ms, together 2.61 ms per window);
+// * the row blocks of 32 stream through: P'[I] (32 x cw) -> LDS (A operand), the old block C[I][J] -> the
+//   accumulators; the operands of row block I+1 are requested before row block I runs its 96 MFMAs per
+//   wave, so the L2 / HBM latency of the operands and of the old block is covered by matrix work;
 // * launch order is XCD-aware: workgroup L runs on XCD L % 8, and the column blocks of one matrix are
 //   consecutive slots of ONE XCD, so that they share P' in that XCD's L2.
-constexpr int CU_THREADS = 512;
+// (Round 2 ran this as one 8-wave workgroup per CU with row blocks of 64: measured alone, MFMA work 2.06 ms and
+// loads + stores 1.56 ms gave 2.61 ms per window of 1000 x n = 500.)
+constexpr int CU_THREADS = 256;
 constexpr int CU_AP = 65;                         // odd pitch of the A tile in LDS: conflict-free fragment reads
 
-__global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
+__global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
     int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cw,
     int only_blk /* >= 0: this column block of every matrix and no other (window pairs, see gj_colupdate2_kernel) */)
 {
-    __shared__ cplx As[2][64 * CU_AP];            // P'[I] of the current and of the next row block
+    __shared__ cplx As[2][32 * CU_AP];            // P'[I] of the current and of the next row block
     __shared__ unsigned char pflag[8192];         // row is a pivot row of this window (its old content counts as zero)
     const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = only_blk >= 0 ? 1 : nblk - 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1010,11 +1010,18 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
     const int* pivrow = piv_all + (size_t)m * 2 * n;
     const int* colof = pivrow + n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 2) * 32, wc = (wave & 3) * 16;       // wave tile 32 x 16 of the 64 x 64 block
+    const int wc = wave * 16;                                    // column tile of this wave (two row tiles per block)
     const int fi = lane & 15, fk = lane >> 4;
     const int col = jb * 64 + wc + fi;
     const bool col_ok = col < n;
     const int colc = col_ok ? col : n - 1;
+    // the matrix base as an explicitly wave-uniform value: scalar base + 32-bit byte offsets in every access of the
+    // pipeline, recomputed where they are used instead of carried as 64-bit pointers (n <= 8192: 16 n^2 < 2^32)
+    const unsigned long long wbits = (unsigned long long)(size_t)W;
+    const char* Wb = reinterpret_cast<const char*>((size_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(wbits >> 32)) << 32) |
+                                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(wbits & 0xffffffffu))));
+    char* Wbw = const_cast<char*>(Wb);
+    const unsigned un = (unsigned)n;
 
     for (int i = tid; i < n; i += CU_THREADS) { const int c = colof[i]; pflag[i] = (c >= c0 && c < c0 + cw) ? 1 : 0; }
     // Q fragments of this wave's column tile: B operand element (k = ks*4 + fk, col)
@@ -1026,54 +1033,55 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
         const bool ok = (k < cw) & col_ok;
         qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
     }
-    // P'[I] (64 rows x 64 k) goes global -> LDS directly (global_load_lds_dwordx4: no register staging): a wave
+    // P'[I] (32 rows x 64 k) goes global -> LDS directly (global_load_lds_dwordx4: no register staging): a wave
     // fills eight rows, one instruction per row -- lane = k, 1 KB contiguous in LDS (pitch 65 stays legal: no
     // instruction crosses a row) and in global memory.  Lanes k >= cw and rows >= n re-read the last valid
     // column / row: finite values that meet zero Q rows / feed discarded output rows.
-    const size_t a_lane = (size_t)c0 + min(lane, cw - 1);
+    const unsigned a_lane = (unsigned)(c0 + min(lane, cw - 1));
     auto fetch_a = [&](int ib, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = wave * 8 + j;
-            const cplx* src = W + (size_t)min(ib * 64 + row, n - 1) * n + a_lane;
+            const unsigned byte_off = ((unsigned)min(ib * 32 + row, n - 1) * un + a_lane) * 16u;
             // (asm: hipcc would drain a builtin LDS-DMA -- vmcnt(0) -- in front of the next ds_read of the OTHER
             //  buffer; the completion of these loads is awaited by the vmcnt(0) of the barrier at the loop top)
             const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
                 (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)&As[buf][row * CU_AP]);   // wave-uniform -> SGPR
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(byte_off), "s"(lds_dst), "s"(Wb) : "memory");
         }
     };
     cplx cv[2][4];
     auto fetch_c = [&](int ib) __attribute__((always_inline)) {
-        const int r0 = ib * 64 + wr + fk;
-        const cplx* cbase = W + (size_t)min(r0, n - 1) * n + colc;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int di = a * 16 + 4 * r;                       // row r0 + di, clamped to the last row
-                cv[a][r] = cbase[(size_t)min(di, max(n - 1 - r0, 0)) * n];
+                const unsigned off = ((unsigned)min(ib * 32 + a * 16 + fk + 4 * r, n - 1) * un + (unsigned)colc) * 16u;
+                cv[a][r] = *reinterpret_cast<const cplx*>(Wb + off);
             }
     };
     fetch_a(0, 0);
     fetch_c(0);
     // Software pipeline over the row blocks (one barrier each).  At the top of iteration ib everything this
-    // wave has in flight is awaited: P'[ib] and C[ib] (requested an iteration ago, in front of 128 MFMAs) and
-    // the stores of block ib-2 (issued an iteration ago as well) -- the results of block ib-1 are still in
-    // registers and are stored only AFTER the requests for block ib+1, so that no wait ever sees a fresh store.
+    // wave has in flight is awaited: P'[ib] and C[ib] (requested an iteration ago, in front of the matrix
+    // instructions) and the stores of block ib-2 (issued an iteration ago as well) -- the results of block ib-1 are
+    // still in registers and are stored only AFTER the requests for block ib+1, so that no wait ever sees a fresh store.
     d4 sr[2], si[2];                      // results of the previous row block, not stored yet
     auto store_block = [&](int ib) __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = ib * 64 + wr + a * 16 + fk + 4 * r;
-                if (gi < n && col_ok) W[(size_t)gi * n + col] = cmake(sr[a][r], si[a][r]);
+                const int gi = ib * 32 + a * 16 + fk + 4 * r;
+                const unsigned off = ((unsigned)gi * un + (unsigned)col) * 16u;
+                if (gi < n && col_ok) *reinterpret_cast<cplx*>(Wbw + off) = cmake(sr[a][r], si[a][r]);
             }
     };
-    for (int ib = 0; ib < nblk; ++ib) {
+    const int nrb = (n + 31) >> 5;
+#pragma unroll 1
+    for (int ib = 0; ib < nrb; ++ib) {
         const int buf = ib & 1;
         d4 cr[2], ci[2], cs[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // 3M form (see gj_update_item): cr = s1, cs = s2, ci = s3
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of P'[ib] (not in hipcc's bookkeeping)
@@ -1082,10 +1090,10 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool z = pflag[min(ib * 64 + wr + a * 16 + fk + 4 * r, n - 1)] != 0;
+                const bool z = pflag[min(ib * 32 + a * 16 + fk + 4 * r, n - 1)] != 0;
                 cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].x + cv[a][r].y;
             }
-        const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
+        const cplx* ab = &As[buf][fi * CU_AP + fk];
         cplx af[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) af[0][a] = ab[a * 16 * CU_AP];
@@ -1093,11 +1101,10 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
         for (int ks = 0; ks < 16; ++ks) {
             const int cur = ks & 1;
             if (ks == 2) {
-                // the requests for row block ib+1 and the stores of row block ib-1 (~250 instructions of address
-                // arithmetic, LDS-DMA set-up and predicated stores) are issued HERE, behind the first 16 MFMAs:
-                // a wave issues them in the shadow of its matrix instructions instead of in front of them
+                // the requests for row block ib+1 and the stores of row block ib-1 are issued HERE, behind the first
+                // matrix instructions: a wave issues them in the shadow of its matrix instructions, not in front of them
                 __builtin_amdgcn_sched_barrier(0);
-                if (ib + 1 < nblk) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
+                if (ib + 1 < nrb) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
                 if (ib > 0) store_block(ib - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1118,7 +1125,7 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) { sr[a][r] = cr[a][r] - cs[a][r]; si[a][r] = ci[a][r] - cr[a][r] - cs[a][r]; }
     }
-    store_block(nblk - 1);
+    store_block(nrb - 1);
 }
 
 // ---- Column-block update with a PAIR of windows, A = [c0, c0+64) and B = [c0+64, c0+64+cwB), in ONE pass over the
@@ -1143,8 +1150,7 @@ __global__ __launch_bounds__(CU_THREADS) void gj_colupdate_kernel(
 // * addresses are 32-bit byte offsets from the wave-uniform matrix base, recomputed where they are used: with
 //   both Q sets in registers there is no room for loop-carried 64-bit pointers (n <= 8192: 16 n^2 < 2^32);
 // * software pipeline and XCD-aware launch order as in gj_colupdate_kernel.
-constexpr int CU4_THREADS = 256;
-__global__ __launch_bounds__(CU4_THREADS, 2) void gj_colupdate2_kernel(
+__global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
     int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cwB)
 {
     __shared__ cplx As2[2][2][16 * CU_AP];        // [buffer][window A / B] P'[I], 16 rows  (66.5 KB)
@@ -1172,7 +1178,7 @@ __global__ __launch_bounds__(CU4_THREADS, 2) void gj_colupdate2_kernel(
     const unsigned un = (unsigned)n;
     const unsigned a_lane = (unsigned)(c0 + lane), b_lane = (unsigned)(cB + min(lane, cwB - 1));
 
-    for (int i = tid; i < n; i += CU4_THREADS) {
+    for (int i = tid; i < n; i += CU_THREADS) {
         const int c = colof[i];
         pflag[i] = (unsigned char)(((c >= c0 && c < cB) ? 1 : 0) | ((c >= cB && c < cB + cwB) ? 2 : 0));
     }
@@ -1382,7 +1388,7 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
                 window(c0, cw);
                 colupdate(c0, cw, jA + 1);                        // A -> block B
                 window(cB, cwB);
-                hipLaunchKernelGGL(gj_colupdate2_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 2)), dim3(CU4_THREADS), 0, s,
+                hipLaunchKernelGGL(gj_colupdate2_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 2)), dim3(CU_THREADS), 0, s,
                                    n, count, Ag, stride, (const int*)pg, c0, cwB);
                 colupdate(cB, cwB, jA);                           // B -> block A (P'A is no longer needed)
                 c0 += WIN;
