@@ -830,16 +830,17 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
 //   columns of the window; the last sub-panel's update is shared by all twelve.
 // Transforms reach every column block in their order (each phase ends in a workgroup barrier); the panel
 // team only touches the columns of the sub-panel it factors, the update team everything else.
-constexpr int LA_PW = 8, LA_NW = 12, LA_THREADS = LA_NW * 64;
-
-template <int NBI>
-__global__ __launch_bounds__(LA_THREADS) void gj_window_la_kernel(
+// n <= 256 runs a lean form (4 panel waves + 2 update waves, TWO workgroups per CU at the same 168-VGPR budget): the
+// panel team's barrier joins four waves instead of eight, of which four would hold no rows, and two workgroups
+// cover each other's pivot chains.
+template <int NBI, int LA_PW, int LA_NW>
+__global__ __launch_bounds__(LA_NW * 64, LA_NW <= 6 ? 3 : 1) void gj_window_la_kernel(
     int n, cplx* __restrict__ bufA, size_t mat_stride,
     int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw,
     unsigned long long* __restrict__ stamps /* diagnostic (NEGF_GJ_STAMPS): workgroup 0, window 1; nullptr in production */)
 {
     using C = GjCfg<NBI, 1, 1, LA_PW, LA_NW>;
-    constexpr int S = NBI, KS = NBI / 4, WT = WIN / 16, PTL = LA_PW * 64;
+    constexpr int S = NBI, KS = NBI / 4, WT = WIN / 16, LA_THREADS = LA_NW * 64;
     static_assert(NBI == 16, "sub-panel = one column tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1369,8 +1370,10 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         hipLaunchKernelGGL(gj_state_init_kernel, dim3(count), dim3(256), 0, s, n, pg, ig);
         auto window = [&](int c0, int cw) {
             unsigned long long* stp = (c0 == WIN && first == 0) ? d_stamps : (unsigned long long*)nullptr;
-            if (NBI == 16 && RPT == 1 && winla)
-                hipLaunchKernelGGL(gj_window_la_kernel<16>, dim3(count), dim3(LA_THREADS), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
+            if (NBI == 16 && RPT == 1 && winla && n <= 256)
+                hipLaunchKernelGGL((gj_window_la_kernel<16, 4, 6>), dim3(count), dim3(6 * 64), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
+            else if (NBI == 16 && RPT == 1 && winla)
+                hipLaunchKernelGGL((gj_window_la_kernel<16, 8, 12>), dim3(count), dim3(12 * 64), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
             else
                 hipLaunchKernelGGL(kern, dim3(count), dim3(PT), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
         };

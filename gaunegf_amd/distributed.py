@@ -16,7 +16,7 @@ must then call GrInt / GrLessInt / calculate_transmission with the same argument
 """
 import numpy as np
 
-_state = {"enabled": False, "group": None}
+_state = {"enabled": False, "group": None, "single_ok": False}
 
 
 def _dist():
@@ -24,24 +24,29 @@ def _dist():
     return dist
 
 
-def enable(group=None):
+def enable(group=None, single_rank_ok=False):
+    """``single_rank_ok``: take the sharded path (device-resident partial sum, the collectives) in a group of ONE
+    rank too -- the RCCL legs then run on a one-GPU box (tests/test_distributed_gpu.py); by default a group of
+    one stays on the local path."""
     dist = _dist()
     if not dist.is_available() or not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
     _state["enabled"] = True
     _state["group"] = group
+    _state["single_ok"] = bool(single_rank_ok)
 
 
 def disable():
     _state["enabled"] = False
     _state["group"] = None
+    _state["single_ok"] = False
 
 
 def is_active():
     if not _state["enabled"]:
         return False
     dist = _dist()
-    return dist.is_initialized() and dist.get_world_size(_state["group"]) > 1
+    return dist.is_initialized() and (dist.get_world_size(_state["group"]) > 1 or _state["single_ok"])
 
 
 def rank_world():

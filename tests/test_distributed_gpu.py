@@ -47,15 +47,20 @@ def _run_all(F, S, g_const, g_chain, E, w):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
+    import torch
     import torch.distributed as dist
     from gaunegf_amd import distributed as D
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LOCAL_RANK"] = "0"                 # both ranks on the one visible GPU
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        D.enable()
+        D.enable(single_rank_ok=(world == 1))
         res = _run_all(*_systems())
         maps = open("/proc/self/maps").read()
         if rank == 0:
@@ -65,12 +70,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_through_the_engine_match_one_process(engine):
+def _spawn_and_compare(world, backend):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -93,4 +98,16 @@ def test_two_ranks_through_the_engine_match_one_process(engine):
     ref = _run_all(*_systems())
     for k in ("gr_const", "gless_const", "gr_chain", "gless_chain", "gr_one"):
         assert np.linalg.norm(res[k] - ref[k]) <= 1e-13 * np.linalg.norm(ref[k]), k
-    assert np.array_equal(res["T"], ref["T"])          # zero-filled all-reduce of per-energy scalars is exact
+    assert np.array_equal(res["T"], ref["T"])          # the all-gather of per-energy scalars is exact
+
+
+def test_two_ranks_through_the_engine_match_one_process(engine):
+    _spawn_and_compare(2, "gloo")
+
+
+def test_rccl_legs_on_one_gpu(engine):
+    """The nccl (= RCCL) branches of gaunegf_amd.distributed -- the in-place all-reduce of the device-resident partial
+    sum (sharded_device_sum) and the device all-gather of per-energy scalars (all_gather_shards) -- in a process
+    group of ONE rank on the one GPU of the box (RCCL refuses two ranks on one device): the same code path a rank of
+    an 8-GPU job runs, collectives included, must reproduce the local integrals."""
+    _spawn_and_compare(1, "nccl")
