@@ -992,7 +992,14 @@ __global__ __launch_bounds__(LA_NW * 64, LA_NW <= 6 ? 3 : 1) void gj_window_la_k
 // (Round 2 ran this as one 8-wave workgroup per CU with row blocks of 64: measured alone, MFMA work 2.06 ms and
 // loads + stores 1.56 ms gave 2.61 ms per window of 1000 x n = 500.)
 constexpr int CU_THREADS = 256;
-constexpr int CU_AP = 65;                         // odd pitch of the A tile in LDS: conflict-free fragment reads
+// Pitch of the A tile in LDS (elements).  A ds_read_b128 serves 16 lanes per cycle in the groups {0-3, 12-15, 20-27}, ...
+// and an A-operand fragment (lane = row fi + 16 k-index fk) then touches the 16-byte bank quads (fi * pitch + fk) mod 16:
+// all distinct for pitch = 2 (mod 4) -- 66 -- while 65 lets (fi 12, fk 0) and (fi 11, fk 1) collide: one conflict
+// cycle per fragment read (round 2's PMC: SQ_LDS_BANK_CONFLICT = SQ_INSTS_MFMA / 3 x ... exactly one per read).
+#ifndef NEGF_CU_AP
+#define NEGF_CU_AP 66
+#endif
+constexpr int CU_AP = NEGF_CU_AP;
 
 __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
     int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cw,
