@@ -16,6 +16,10 @@
 // Interleaved (re,im) storage means ONE 16-byte LDS read gives a lane both the
 // real and the imaginary operand of its element.
 //
+// opB = 3: op(B) = B^H AND the caller states that the product is Hermitian (G Gamma G^H with Gamma = i (Sigma - Sigma^H),
+// integrate.py:79-81: X G^H with X = G Gamma): only the block tiles on and above the diagonal are computed, every block
+// above it also stores its conjugate transpose -- the same sums, each taken once (n = 1000: 136 of 256 block tiles).
+//
 // Workgroup = 256 threads = 4 waves; block tile 64 x 64, wave tile 32 x 32
 // (2 x 2 MFMA tiles, 64 accumulator VGPRs), K tile 16 staged through LDS.
 #include "negf_common.h"
@@ -29,12 +33,16 @@ static constexpr int ZG_BPITCH = ZG_BN + 1;
 __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
     int M, int N, int K,
     const cplx* __restrict__ Aall, int lda, size_t strideA,
-    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
+    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB_arg,
     cplx* __restrict__ Call, int ldc, size_t strideC)
 {
     __shared__ cplx As[ZG_BM * ZG_APITCH];      // As[i][k]
     __shared__ cplx Bs[ZG_BK * ZG_BPITCH];      // Bs[k][j]  (already op()'ed)
 
+    const bool herm = (opB_arg & 2) != 0;       // Hermitian product: blocks below the diagonal are mirrored, not computed
+    const int opB = opB_arg & 1;
+    if (herm && blockIdx.y > blockIdx.x) return;
+    const bool mirror = herm && blockIdx.y < blockIdx.x;
     const int b = blockIdx.z;
     const cplx* A = Aall + (size_t)b * strideA;
     const cplx* B = Ball + (size_t)b * strideB;
@@ -132,8 +140,11 @@ __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int gi = row0 + wr + a * 16 + fk + 4 * r;
                 const int gj = col0 + wc + c * 16 + fi;
-                if (gi < M && gj < N)
-                    C[(size_t)gi * ldc + gj] = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
+                if (gi < M && gj < N) {
+                    const cplx v = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
+                    C[(size_t)gi * ldc + gj] = v;
+                    if (mirror) C[(size_t)gj * ldc + gi] = cconj(v);     // (fk = 0..3: 64 contiguous bytes per row gj)
+                }
             }
 }
 
@@ -158,11 +169,15 @@ __host__ __device__ inline void zf_block_range(int tiles, int nblk, int b, int* 
 __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
     int M, int N, int K, int nbm, int nbn,
     const cplx* __restrict__ Aall, int lda, size_t strideA,
-    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
+    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB_arg,
     cplx* __restrict__ Call, int ldc, size_t strideC)
 {
     __shared__ cplx As[ZF_ROWS * ZF_APITCH];     // As[i][k]
     __shared__ cplx Bs[ZG_BK * ZF_BPITCH];       // Bs[k][j]  (already op()'ed)
+    const bool herm = (opB_arg & 2) != 0;        // see zgemm_mfma_kernel (M == N: the row and column blocks coincide)
+    const int opB = opB_arg & 1;
+    if (herm && blockIdx.y > blockIdx.x) return;
+    const bool mirror = herm && blockIdx.y < blockIdx.x;
     const int b = blockIdx.z;
     const cplx* A = Aall + (size_t)b * strideA;
     const cplx* B = Ball + (size_t)b * strideB;
@@ -240,7 +255,11 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = row0 + ti * 16 + fk + 4 * r, gj = col0 + tj * 16 + fi;
-                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
+                if (gi < M && gj < N) {
+                    const cplx v = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
+                    C[(size_t)gi * ldc + gj] = v;
+                    if (mirror) C[(size_t)gj * ldc + gi] = cconj(v);
+                }
             }
         }
     }
@@ -252,9 +271,10 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
 __global__ __launch_bounds__(256) void zgemm_valu_kernel(
     int M, int N, int K,
     const cplx* __restrict__ Aall, int lda, size_t strideA,
-    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB,
+    const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB_arg,
     cplx* __restrict__ Call, int ldc, size_t strideC)
 {
+    const int opB = opB_arg & 1;                 // (the Hermitian hint is not used: every element is computed)
     __shared__ cplx As[32][17];
     __shared__ cplx Bs[16][33];
     const int b = blockIdx.z;
@@ -318,6 +338,10 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
                   cplx* C, int ldc, size_t strideC)
 {
     if (M <= 0 || N <= 0 || nb <= 0) return;
+    if ((opB & 2) && M != N) opB &= 1;           // the Hermitian form needs a square result
+    static int herm_env = -1;                    // NEGF_ZGEMM_HERM=0: compute Hermitian products in full (A/B, tests)
+    if (herm_env < 0) { const char* e = getenv("NEGF_ZGEMM_HERM"); herm_env = e ? atoi(e) : 1; }
+    if (!herm_env) opB &= 1;
     if (zgemm_algo() == 1) {
         dim3 grid((N + 31) / 32, (M + 31) / 32, nb);
         hipLaunchKernelGGL(zgemm_valu_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,

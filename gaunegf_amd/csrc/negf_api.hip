@@ -820,7 +820,7 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
                 ProfScope ps(c, "zgemm");
                 launch_gather_block(c->stream, n, n, g.K, nb, c->G, n2, nullptr, g.idx, Gc, n2);
                 launch_zgemm(c->stream, n, g.K, g.K, nb, Gc, g.K, n2, g.mat, g.K, g.stride, 0, X, g.K, n2);
-                launch_zgemm(c->stream, n, n, g.K, nb, X, g.K, n2, Gc, g.K, n2, 1, c->W1, n, n2);
+                launch_zgemm(c->stream, n, n, g.K, nb, X, g.K, n2, Gc, g.K, n2, 3, c->W1, n, n2);   // Hermitian result
             }
             ProfScope ps(c, "accumulate");
             launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);
@@ -833,7 +833,9 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
             ProfScope ps(c, "zgemm");
             // W2 = G Gamma ; W1 = W2 G^H   (integrate.py:81)
             launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, gam, n, gs, 0, c->W2, n, n2);
-            launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, 1, c->W1, n, n2);
+            // (G Gamma G^H is Hermitian -- Gamma = i (Sigma - Sigma^H) is, element by element -- : upper block tiles
+            //  computed, lower ones mirrored)
+            launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, 3, c->W1, n, n2);
         }
         ProfScope ps(c, "accumulate");
         launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);

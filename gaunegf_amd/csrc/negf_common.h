@@ -195,7 +195,8 @@ void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx
 size_t accumulate_scratch_elems(int n2, int nb);
 
 // C[b] (M x N) = A[b] (M x K) * op(B[b]);  a batch stride of 0 broadcasts one matrix.
-// opB: 0 -> B is K x N (ldb >= N); 1 -> op(B) = B^H with B stored N x K (ldb >= K).
+// opB: 0 -> B is K x N (ldb >= N); 1 -> op(B) = B^H with B stored N x K (ldb >= K); 3 -> as 1, and the caller states
+// that the (square) product is Hermitian: block tiles above the diagonal are computed and mirrored, those below skipped.
 void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
                   const cplx* A, int lda, size_t strideA,
                   const cplx* B, int ldb, size_t strideB, int opB,

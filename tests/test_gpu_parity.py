@@ -83,8 +83,10 @@ def test_windowed_inverse_batch_shapes(engine, N, M):
         assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9, (N, M, k)
 
 
-@pytest.mark.parametrize("N,M", [(12, 12), (60, 100), (200, 64)])
+@pytest.mark.parametrize("N,M", [(12, 12), (60, 100), (200, 64), (150, 6), (330, 5)])
 def test_GrInt_GrLessInt_const_sigma(engine, N, M):
+    # (G Gamma G^H runs as a Hermitian product: block tiles above the diagonal computed and mirrored -- one block
+    #  at N <= 64, the flexible-block kernel at N = 200, 3 x 3 and 6 x 6 blocks of 64 with a ragged edge at 150 / 330)
     from gaunegf_amd.integrate import GrInt, GrLessInt
     F, S, g_dev, g_ref = _const_provider(N, 7 + N)
     E, w = oracle.contour_grid(-4.0, 0.2, M if M % 2 == 0 else M + 1, 300.0)
