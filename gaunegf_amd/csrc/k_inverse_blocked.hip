@@ -1001,11 +1001,16 @@ constexpr int CU_THREADS = 256;
 #endif
 constexpr int CU_AP = NEGF_CU_AP;
 
-__global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
+// NW = 4: the lean form above.  NW = 8: one workgroup of eight waves per CU with row blocks of 64 (round 2's shape) for
+// launches that do not fill the chip (fewer workgroups than CUs -- the small per-GPU batches of a sharded grid): the
+// column block is then the unit of parallelism, and eight waves take it through in half the time of four.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
     int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cw,
     int only_blk /* >= 0: this column block of every matrix and no other (window pairs, see gj_colupdate2_kernel) */)
 {
-    __shared__ cplx As[2][32 * CU_AP];            // P'[I] of the current and of the next row block
+    constexpr int RB = 8 * NW, THREADS = NW * 64;   // rows of a row block (a wave fills eight rows and owns 32 x 16 of them)
+    __shared__ cplx As[2][RB * CU_AP];            // P'[I] of the current and of the next row block
     __shared__ unsigned char pflag[8192];         // row is a pivot row of this window (its old content counts as zero)
     const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = only_blk >= 0 ? 1 : nblk - 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1018,7 +1023,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
     const int* pivrow = piv_all + (size_t)m * 2 * n;
     const int* colof = pivrow + n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wc = wave * 16;                                    // column tile of this wave (two row tiles per block)
+    const int wr = (wave >> 2) * 32, wc = (wave & 3) * 16;       // wave tile 32 x 16 of the RB x 64 block
     const int fi = lane & 15, fk = lane >> 4;
     const int col = jb * 64 + wc + fi;
     const bool col_ok = col < n;
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
     char* Wbw = const_cast<char*>(Wb);
     const unsigned un = (unsigned)n;
 
-    for (int i = tid; i < n; i += CU_THREADS) { const int c = colof[i]; pflag[i] = (c >= c0 && c < c0 + cw) ? 1 : 0; }
+    for (int i = tid; i < n; i += THREADS) { const int c = colof[i]; pflag[i] = (c >= c0 && c < c0 + cw) ? 1 : 0; }
     // Q fragments of this wave's column tile: B operand element (k = ks*4 + fk, col)
     cplx qf[16];
 #pragma unroll
@@ -1041,7 +1046,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
         const bool ok = (k < cw) & col_ok;
         qf[ks] = cmake(ok ? v.x : 0.0, ok ? v.y : 0.0);
     }
-    // P'[I] (32 rows x 64 k) goes global -> LDS directly (global_load_lds_dwordx4: no register staging): a wave
+    // P'[I] (RB rows x 64 k) goes global -> LDS directly (global_load_lds_dwordx4: no register staging): a wave
     // fills eight rows, one instruction per row -- lane = k, 1 KB contiguous in LDS (pitch 65 stays legal: no
     // instruction crosses a row) and in global memory.  Lanes k >= cw and rows >= n re-read the last valid
     // column / row: finite values that meet zero Q rows / feed discarded output rows.
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = wave * 8 + j;
-            const unsigned byte_off = ((unsigned)min(ib * 32 + row, n - 1) * un + a_lane) * 16u;
+            const unsigned byte_off = ((unsigned)min(ib * RB + row, n - 1) * un + a_lane) * 16u;
             // (asm: hipcc would drain a builtin LDS-DMA -- vmcnt(0) -- in front of the next ds_read of the OTHER
             //  buffer; the completion of these loads is awaited by the vmcnt(0) of the barrier at the loop top)
             const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -1066,7 +1071,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned off = ((unsigned)min(ib * 32 + a * 16 + fk + 4 * r, n - 1) * un + (unsigned)colc) * 16u;
+                const unsigned off = ((unsigned)min(ib * RB + wr + a * 16 + fk + 4 * r, n - 1) * un + (unsigned)colc) * 16u;
                 cv[a][r] = *reinterpret_cast<const cplx*>(Wb + off);
             }
     };
@@ -1082,12 +1087,12 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int gi = ib * 32 + a * 16 + fk + 4 * r;
+                const int gi = ib * RB + wr + a * 16 + fk + 4 * r;
                 const unsigned off = ((unsigned)gi * un + (unsigned)col) * 16u;
                 if (gi < n && col_ok) *reinterpret_cast<cplx*>(Wbw + off) = cmake(sr[a][r], si[a][r]);
             }
     };
-    const int nrb = (n + 31) >> 5;
+    const int nrb = (n + RB - 1) / RB;
 #pragma unroll 1
     for (int ib = 0; ib < nrb; ++ib) {
         const int buf = ib & 1;
@@ -1098,10 +1103,10 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate_kernel(
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool z = pflag[min(ib * 32 + a * 16 + fk + 4 * r, n - 1)] != 0;
+                const bool z = pflag[min(ib * RB + wr + a * 16 + fk + 4 * r, n - 1)] != 0;
                 cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].x + cv[a][r].y;
             }
-        const cplx* ab = &As[buf][fi * CU_AP + fk];
+        const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
         cplx af[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) af[0][a] = ab[a * 16 * CU_AP];
@@ -1368,6 +1373,10 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     if (winla < 0) { const char* e = getenv("NEGF_GJ_WINLA"); winla = e ? atoi(e) : 1; }
     static int pair = -1;                // windows in pairs (one pass over the other column blocks per pair); 0: one by one
     if (pair < 0) { const char* e = getenv("NEGF_GJ_PAIR"); pair = e ? atoi(e) : 1; }
+    static long pair_min = -1, fat_max = -1, fat_total_max = -1;
+    if (pair_min < 0) { const char* e = getenv("NEGF_GJ_PAIR_MIN"); pair_min = e ? atol(e) : 352; }
+    if (fat_max < 0) { const char* e = getenv("NEGF_GJ_FAT_MAX"); fat_max = e ? atol(e) : 256; }
+    if (fat_total_max < 0) { const char* e = getenv("NEGF_GJ_FAT_TOTAL_MAX"); fat_total_max = e ? atol(e) : 2000; }
     const int nblk = (n + 63) / 64;
     // the chain of one group of matrices: per window the panel kernel (one workgroup per matrix: a latency chain
     // that covers at most `count` CUs) and the column-block update (throughput-bound), then the gather
@@ -1386,12 +1395,25 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         };
         auto colupdate = [&](int c0, int cw, int only_blk) {
             const int blocks = only_blk >= 0 ? 1 : nblk - 1;
-            hipLaunchKernelGGL(gj_colupdate_kernel, dim3(8 * ((count + 7) / 8) * blocks), dim3(CU_THREADS), 0, s,
-                               n, count, Ag, stride, (const int*)pg, c0, cw, only_blk);
+            const dim3 grid(8 * ((count + 7) / 8) * blocks);
+            // eight waves per column block where the launch has fewer workgroups than the chip has CUs AND the whole
+            // batch (all stream groups together) leaves the chip room: there a column block's latency counts, not the
+            // CU's throughput (MI355X, inverse ms, lean / fat: 61 x N = 800 8.87 / 7.57, 64 x N = 1000 14.40 / 13.83,
+            // 250 x N = 500 6.81 / 6.49 (single-block launches of the pairs); but 1000 x N = 500 25.4 / 29.8: a fat
+            // workgroup takes a CU's whole LDS and shuts the other groups' kernels out)
+            if ((long)count * blocks > fat_max || (long)nb * nblk > fat_total_max)
+                hipLaunchKernelGGL(gj_colupdate_kernel<4>, grid, dim3(256), 0, s, n, count, Ag, stride, (const int*)pg, c0, cw, only_blk);
+            else
+                hipLaunchKernelGGL(gj_colupdate_kernel<8>, grid, dim3(512), 0, s, n, count, Ag, stride, (const int*)pg, c0, cw, only_blk);
         };
+        // Pairs pay where the update is throughput-bound (they halve its traffic); a small group of matrices is a
+        // latency chain of kernels, to which a pair adds two single-block launches: measured cross-over (MI355X,
+        // workgroups of the fused kernel per group) 61 x N = 800 in four groups (165: 8.87 ms one by one, 9.25 in
+        // pairs), 250 x N = 500 (372: 6.91 / 6.81), 128 x N = 1000 (448: 24.0 / 22.95)
+        const bool use_pairs = pair && nblk >= 3 && (long)count * (nblk - 2) >= pair_min;
         for (int c0 = 0; c0 < n; c0 += WIN) {
             const int cw = min(WIN, n - c0);
-            if (pair && nblk >= 3 && c0 + WIN < n) {
+            if (use_pairs && c0 + WIN < n) {
                 // windows A = [c0, c0 + 64) and B = the next one as a pair: every block outside the two is read and
                 // written once for both (gj_colupdate2_kernel)
                 const int cB = c0 + WIN, cwB = min(WIN, n - cB), jA = c0 / WIN;

@@ -83,6 +83,24 @@ def test_windowed_inverse_batch_shapes(engine, N, M):
         assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9, (N, M, k)
 
 
+@pytest.mark.parametrize("N,M", [(300, 480), (449, 640)])
+def test_windowed_inverse_large_batches(engine, N, M):
+    """Batches large enough for the throughput configuration of the windowed inverse: four stream groups of >= 120
+    matrices, windows in PAIRS (fused update kernel, two lean workgroups per CU) and the lean single-window update
+    -- small batches run the windows one by one with eight-wave workgroups.  N = 300: two pairs and an odd last window of
+    44 columns; N = 449: four pairs, the last window one column wide.  Checked through the weighted sum over all
+    energies (one wrong matrix among M would show at 1/M) and through residuals of a sample."""
+    from gaunegf_amd.integrate import GrInt, GrBatch
+    F, S, g_dev, g_ref = _const_provider(N, 500 + N, nc=20)
+    E = np.linspace(-2.5, 2.5, M) + 0.03j
+    w = (np.cos(np.arange(M)) + 1.5) / M + 0.0j
+    assert rel_fro(GrInt(F, S, g_dev, E, w), oracle.GrInt(F, S, g_ref, E, w)) < TOL
+    G = GrBatch(F, S, g_dev, E)
+    for k in (0, 1, M // 3, M // 2, M - 2, M - 1):
+        A = E[k] * S - F - np.asarray(g_ref.sigmaTot(E[k]))
+        assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9, (N, M, k)
+
+
 @pytest.mark.parametrize("N,M", [(12, 12), (60, 100), (200, 64), (150, 6), (330, 5)])
 def test_GrInt_GrLessInt_const_sigma(engine, N, M):
     # (G Gamma G^H runs as a Hermitian product: block tiles above the diagonal computed and mirrored -- one block
