@@ -195,6 +195,19 @@ void launch_gather_block(hipStream_t st, int n, int nr, int nc, int nb, const cp
                        cidx, out, out_stride);
 }
 
+// out = a + b (elementwise): F + Sigma_tot of the constant providers when the resident system changes
+__global__ __launch_bounds__(EW_THREADS) void cadd_kernel(size_t count, const cplx* __restrict__ a, const cplx* __restrict__ b, cplx* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i < count) out[i] = cadd(a[i], b[i]);
+}
+
+void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cplx* out)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(cadd_kernel, dim3((unsigned)((count + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, st, count, a, b, out);
+}
+
 // -------------------------------------------------------------- accumulate
 // acc[i] += sum_b w[b] * X[b][i] in a FIXED order (bitwise reproducible from run to run):
 // the batch is cut into chunks of ACC_CHUNK energies; pass 1 reduces each chunk into

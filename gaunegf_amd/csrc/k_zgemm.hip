@@ -41,15 +41,24 @@ __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
 
     const bool herm = (opB_arg & 2) != 0;       // Hermitian product: blocks below the diagonal are mirrored, not computed
     const int opB = opB_arg & 1;
-    if (herm && blockIdx.y > blockIdx.x) return;
-    const bool mirror = herm && blockIdx.y < blockIdx.x;
+    // Hermitian form: the grid is the upper triangle itself, row by row (gridDim.x = T (T + 1) / 2 block tiles) -- a
+    // full T x T grid with the lower blocks returning at once loads the XCDs (block index mod 8) unevenly and ran
+    // SLOWER than the full product (n = 1000: 67 ms against 52)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (herm) {
+        const int T = (N + ZG_BN - 1) / ZG_BN;
+        int t = blockIdx.x; by = 0;
+        while (t >= T - by) { t -= T - by; ++by; }
+        bx = by + t;
+    }
+    const bool mirror = herm && by < bx;
     const int b = blockIdx.z;
     const cplx* A = Aall + (size_t)b * strideA;
     const cplx* B = Ball + (size_t)b * strideB;
     cplx* C = Call + (size_t)b * strideC;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.y * ZG_BM, col0 = blockIdx.x * ZG_BN;
+    const int row0 = by * ZG_BM, col0 = bx * ZG_BN;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;   // wave tile origin in the block tile
     const int fi = lane & 15, fk = lane >> 4;
 
@@ -140,12 +149,38 @@ __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int gi = row0 + wr + a * 16 + fk + 4 * r;
                 const int gj = col0 + wc + c * 16 + fi;
-                if (gi < M && gj < N) {
-                    const cplx v = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
-                    C[(size_t)gi * ldc + gj] = v;
-                    if (mirror) C[(size_t)gj * ldc + gi] = cconj(v);     // (fk = 0..3: 64 contiguous bytes per row gj)
-                }
+                if (gi < M && gj < N)
+                    C[(size_t)gi * ldc + gj] = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
             }
+    if (mirror) {
+        // the conjugate transpose of the block, transposed through LDS (the A staging area is free after the K loop:
+        // one 16 x 17 patch per wave) so that 16 lanes again write 256 contiguous bytes -- written straight from the
+        // accumulator layout the mirror image is 64-byte pieces in 16 different rows, and the two Hermitian products
+        // of C5 took 67 ms instead of 52 for half the matrix work
+        cplx* T = As + wave * (16 * ZG_APITCH);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    T[fi * ZG_APITCH + fk + 4 * r] = cmake(s1[a][c][r] - s2[a][c][r], -(s3[a][c][r] - s1[a][c][r] - s2[a][c][r]));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // T[j][i] = conj(tile[i][j]); this lane reads row j = fk + 4r, column i = fi
+                    const int gr = col0 + wc + c * 16 + fk + 4 * r;      // row of the mirror image
+                    const int gc = row0 + wr + a * 16 + fi;              // its column
+                    const cplx v = T[(fk + 4 * r) * ZG_APITCH + fi];
+                    if (gr < N && gc < M) C[(size_t)gr * ldc + gc] = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+    }
 }
 
 // ---- flexible-block version for shapes the 64 x 64 block tile pads badly (n = 200: 13 tiles of 16 per
@@ -174,17 +209,23 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
 {
     __shared__ cplx As[ZF_ROWS * ZF_APITCH];     // As[i][k]
     __shared__ cplx Bs[ZG_BK * ZF_BPITCH];       // Bs[k][j]  (already op()'ed)
+    __shared__ cplx Ts[ZF_WAVES * 16 * 17];      // per-wave transpose patch of the Hermitian mirror image
     const bool herm = (opB_arg & 2) != 0;        // see zgemm_mfma_kernel (M == N: the row and column blocks coincide)
     const int opB = opB_arg & 1;
-    if (herm && blockIdx.y > blockIdx.x) return;
-    const bool mirror = herm && blockIdx.y < blockIdx.x;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (herm) {                                  // the grid is the upper triangle of the nbn x nbn blocks, row by row
+        int t = blockIdx.x; by = 0;
+        while (t >= nbn - by) { t -= nbn - by; ++by; }
+        bx = by + t;
+    }
+    const bool mirror = herm && by < bx;
     const int b = blockIdx.z;
     const cplx* A = Aall + (size_t)b * strideA;
     const cplx* B = Ball + (size_t)b * strideB;
     cplx* C = Call + (size_t)b * strideC;
     int tr0, tm, tc0, tn;
-    zf_block_range((M + 15) >> 4, nbm, blockIdx.y, &tr0, &tm);
-    zf_block_range((N + 15) >> 4, nbn, blockIdx.x, &tc0, &tn);
+    zf_block_range((M + 15) >> 4, nbm, by, &tr0, &tm);
+    zf_block_range((N + 15) >> 4, nbn, bx, &tc0, &tn);
     const int row0 = tr0 * 16, col0 = tc0 * 16, rows = tm * 16, cols = tn * 16, ntiles = tm * tn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fk = lane >> 4;
@@ -255,11 +296,25 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int gi = row0 + ti * 16 + fk + 4 * r, gj = col0 + tj * 16 + fi;
-                if (gi < M && gj < N) {
-                    const cplx v = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
-                    C[(size_t)gi * ldc + gj] = v;
-                    if (mirror) C[(size_t)gj * ldc + gi] = cconj(v);
+                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
+            }
+            if (mirror) {                                    // (wave-uniform) the conjugate transpose, through LDS: see zgemm_mfma_kernel
+                cplx* T = Ts + wave * (16 * 17);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    T[fi * 17 + fk + 4 * r] = cmake(s1[s][r] - s2[s][r], -(s3[s][r] - s1[s][r] - s2[s][r]));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = col0 + tj * 16 + fk + 4 * r, gc = row0 + ti * 16 + fi;
+                    const cplx v = T[(fk + 4 * r) * 17 + fi];
+                    if (gr < N && gc < M) C[(size_t)gr * ldc + gc] = v;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
     }
@@ -357,10 +412,12 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
         if (flex_env == 2 || (flex_env == 1 && padded)) {
             const int nbm = (int)((tm16 + ZF_MAXT - 1) / ZF_MAXT), nbn = (int)((tn16 + ZF_MAXT - 1) / ZF_MAXT);
             dim3 grid(nbn, nbm, nb);
+            if (opB & 2) grid = dim3(nbn * (nbn + 1) / 2, 1, nb);
             hipLaunchKernelGGL(zgemm_flex_kernel, grid, dim3(ZF_THREADS), 0, st, M, N, K, nbm, nbn, A, lda, strideA,
                                B, ldb, strideB, opB, C, ldc, strideC);
         } else {
             dim3 grid((unsigned)bn64, (unsigned)bm64, nb);
+            if (opB & 2) grid = dim3((unsigned)(bn64 * (bn64 + 1) / 2), 1, nb);
             hipLaunchKernelGGL(zgemm_mfma_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
                                strideB, opB, C, ldc, strideC);
         }

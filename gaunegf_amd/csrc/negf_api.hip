@@ -475,7 +475,9 @@ void negf_destroy(negf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto* p : c->providers) free_provider(p);
     free_workspace(c); free_mbuffers(c);
-    dev_free(c->d_F); dev_free(c->d_S); dev_free(c->d_acc);
+    for (auto& sl : c->sys) { dev_free(sl.dF); dev_free(sl.dS); }
+    c->d_F = c->d_S = nullptr;
+    dev_free(c->d_acc);
     prof_resolve(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -515,32 +517,53 @@ int negf_set_system(negf_ctx* c, int n, const double* F, const double* S)
     if (!c || n <= 0 || !F || !S) return NEGF_EINVAL;
     NEGF_HIP_CHECK(hipSetDevice(c->device));
     NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const size_t n2 = (size_t)n * n;
+    int rc;
     if (n != c->n) {
         // providers are tied to the matrix dimension
         for (auto*& p : c->providers) { free_provider(p); p = nullptr; }
         free_workspace(c);
-        dev_free(c->d_F); dev_free(c->d_S); dev_free(c->d_acc);
+        for (auto& sl : c->sys) { dev_free(sl.dF); dev_free(sl.dS); sl.valid = false; sl.hF.clear(); sl.hS.clear(); }
+        c->d_F = c->d_S = nullptr; c->sys_cur = -1;
+        dev_free(c->d_acc);
         c->n = n;
-        const size_t n2 = (size_t)n * n;
-        int rc;
-        if ((rc = dev_alloc(&c->d_F, n2))) return rc;
-        if ((rc = dev_alloc(&c->d_S, n2))) return rc;
         if ((rc = dev_alloc(&c->d_acc, n2))) return rc;
     }
-    const size_t n2 = (size_t)n * n;
-    int rc;
-    if ((rc = upload(c, c->d_F, reinterpret_cast<const cplx*>(F), n2))) return rc;
-    if ((rc = upload(c, c->d_S, reinterpret_cast<const cplx*>(S), n2))) return rc;
-    // constant providers cache F + Sigma_tot: refresh them for the new F
-    for (auto* p : c->providers) {
-        if (p && p->kind == SK_CONST) {
-            std::vector<cplx> h(n2), st(n2);
-            if ((rc = download(c, st.data(), p->d_const_tot, n2))) return rc;
-            const cplx* Fh = reinterpret_cast<const cplx*>(F);
-            for (size_t i = 0; i < n2; ++i) h[i] = cadd(Fh[i], st[i]);
-            if ((rc = upload(c, p->d_hbase, h.data(), n2))) return rc;
-        }
+    const cplx* Fh = reinterpret_cast<const cplx*>(F);
+    const cplx* Sh = reinterpret_cast<const cplx*>(S);
+    // one of the systems already on the device?  (bitwise comparison with the host copies)
+    int slot = -1;
+    for (int k = 0; k < negf_ctx::NEGF_SYS_SLOTS && slot < 0; ++k) {
+        const auto& sl = c->sys[k];
+        if (sl.valid && sl.hF.size() == n2 && std::memcmp(sl.hF.data(), Fh, n2 * sizeof(cplx)) == 0 &&
+            std::memcmp(sl.hS.data(), Sh, n2 * sizeof(cplx)) == 0) slot = k;
     }
+    if (slot >= 0 && slot == c->sys_cur) return NEGF_OK;             // resident: nothing to do
+    if (slot < 0) {
+        // least recently used slot (an empty one first)
+        slot = 0;
+        for (int k = 1; k < negf_ctx::NEGF_SYS_SLOTS; ++k)
+            if (!c->sys[k].valid ? c->sys[slot].valid : (c->sys[slot].valid && c->sys[k].used < c->sys[slot].used)) slot = k;
+        auto& sl = c->sys[slot];
+        sl.valid = false;
+        if (!sl.dF && (rc = dev_alloc(&sl.dF, n2))) return rc;
+        if (!sl.dS && (rc = dev_alloc(&sl.dS, n2))) return rc;
+        if ((rc = upload(c, sl.dF, Fh, n2))) return rc;
+        if ((rc = upload(c, sl.dS, Sh, n2))) return rc;
+        sl.hF.assign(Fh, Fh + n2);
+        sl.hS.assign(Sh, Sh + n2);
+        sl.valid = true;
+    }
+    c->sys[slot].used = ++c->sys_clock;
+    c->sys_cur = slot;
+    c->d_F = c->sys[slot].dF;
+    c->d_S = c->sys[slot].dS;
+    // constant providers cache F + Sigma_tot: refresh them for the resident F (on the device, same rounding as
+    // the host sum at creation: one IEEE addition per component)
+    for (auto* p : c->providers)
+        if (p && p->kind == SK_CONST) launch_cadd(c->stream, n2, c->d_F, p->d_const_tot, p->d_hbase);
+    NEGF_HIP_CHECK(hipGetLastError());
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
     return NEGF_OK;
 }
 

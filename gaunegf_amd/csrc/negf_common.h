@@ -120,8 +120,16 @@ struct negf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int n = 0;
-    cplx* d_F = nullptr;
+    cplx* d_F = nullptr;           // the resident system: aliases of sys[sys_cur]
     cplx* d_S = nullptr;
+    // the last NEGF_SYS_SLOTS systems handed to negf_set_system stay on the device (with a host copy to recognise
+    // them by): front-ends that alternate between two systems -- the two spin blocks of a blockdiag(alpha, beta)
+    // Fock matrix, scf.py:177-180 -- re-select instead of re-uploading
+    struct SysSlot { cplx* dF = nullptr; cplx* dS = nullptr; std::vector<cplx> hF, hS; unsigned long long used = 0; bool valid = false; };
+    static constexpr int NEGF_SYS_SLOTS = 2;
+    SysSlot sys[NEGF_SYS_SLOTS];
+    int sys_cur = -1;
+    unsigned long long sys_clock = 0;
     int batch_user = 0;            // 0 = auto
     int batch = 0;                 // allocated workspace batch
     bool transmission_seen = false; // negf_transmission[_dev] has run on this context: size the workspace for it
@@ -192,6 +200,7 @@ bool inverse_blocked_supported(int n);
 // acc += sum_b w[b] * X[b]   (fixed summation order, deterministic); `part` is scratch of
 // accumulate_scratch_elems(n2, nb) elements (<= nb * n2 / 32)
 void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc, cplx* part);
+void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cplx* out);
 size_t accumulate_scratch_elems(int n2, int nb);
 
 // C[b] (M x N) = A[b] (M x K) * op(B[b]);  a batch stride of 0 broadcasts one matrix.

@@ -67,7 +67,8 @@ class surfGTest:
             return None
         # the halves (and the CONST providers they lower to) are kept with the object: GrInt / GrLessInt ask for
         # them on every call, and creating / freeing device providers each time dominated small integrals
-        key = (N, tuple((id(sg), sg.shape, complex(np.sum(sg)), float(np.sum(np.abs(sg)))) for sg in self.sig))
+        from .engine import fingerprint
+        key = (N, tuple((id(sg), sg.shape, fingerprint(sg)) for sg in self.sig))
         cached = getattr(self, "_split_cache", None)
         if cached is not None and cached[0] == key:
             for h in cached[1] or ():

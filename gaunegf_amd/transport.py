@@ -90,10 +90,10 @@ class SigmaCalculator:
         their sum as a single contact (DOS).  The entry is keyed on the engine generation (a change of the
         matrix dimension drops every provider in the library) and on a checksum of the arrays, which the
         caller owns and may change between calls."""
-        import zlib
+        from .engine import fingerprint
         a1 = np.ascontiguousarray(self._static(self.sig1))
         a2 = np.ascontiguousarray(self._static(self.sig2))
-        stamp = (a1.shape, a2.shape, zlib.crc32(a1.view(np.uint8).reshape(-1)), zlib.crc32(a2.view(np.uint8).reshape(-1)))
+        stamp = (a1.shape, a2.shape, fingerprint(a1), fingerprint(a2))
         cache = self.__dict__.setdefault("_lowered", {})
         key = (id(engine), getattr(engine, "generation", 0), what, spin if spin in ('u', 'ro', 'g') else 'r', matrix_size)
         hit = cache.get(key)
