@@ -1144,30 +1144,31 @@ __global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
 // ---- Column-block update with a PAIR of windows, A = [c0, c0+64) and B = [c0+64, c0+64+cwB), in ONE pass over the
 // column block: the single-window update above reads and writes every block outside the window once per window
 // (1000 matrices of n = 500: 7 GB per window, as much time in loads and stores as in matrix instructions); with
-// the pair fused the old block is read once, takes both rank-64 updates in the accumulators and is written once.
-//     W' = keepA(W) + P'A QA            QA = rows pivA of W  (block J, in place)
-//     W''= keepB(W') + P'B QB           QB = rows pivB of W' = W[pivB] + P'A[pivB] QA   (pivB rows are no pivA rows)
-// The launch sequence of a pair (gj_large_launch): window kernel A; single-window update of block B alone;
-// window kernel B (its columns are up to date with A); THIS kernel on all blocks but A and B; single-window
-// update with B of block A alone (whose columns -- P'A -- this kernel reads and must find untouched).
+// the pair fused the old block is read once, takes a rank-128 update in the accumulators and is written once.
+// Window by window,
+//     W' = keepA(W) + P'A QA               QA = rows pivA of W                (keepX: the pivot rows of X count as zero)
+//     W''= keepB(W') + P'B QB'             QB' = rows pivB of W' = W[pivB] + P'A[pivB] QA
+// and, multiplied out,
+//     W''= keepAB(W) + P''A QA + P'B QB    QB = rows pivB of W (raw),   P''A = keepB(P'A) + P'B P'A[pivB]
+// where P''A is nothing but block A after ITS update with window B: the pair acts as one 128-column window whose
+// transform is [P''A | P'B], and both Q sets are read in place from the untouched block.  Launch sequence of a pair
+// (gj_large_launch): window kernel A; single-window update of block B alone; window kernel B (its columns are up to
+// date with A); single-window update with B of block A alone (-> P''A); THIS kernel on all blocks but A and B.
+// (A first version kept P'A and corrected QB on the matrix cores -- the accumulator layout of the FP64 16x16x4
+// instruction is the B-operand fragment of the next product -- : one eighth more matrix work at n = 500.)
 // * TWO lean workgroups per CU (4 waves each, one column tile per wave): the two run their barriers and operand
 //   waits independently of each other (one 8-wave workgroup per CU with row blocks of 32: N = 500 x 1000 26.8 ms
 //   against 25.7, N = 1000 167 against 154);
-// * QB is formed first: the 64 pivot rows of B as one virtual row block (their P'A rows staged in LDS), the
-//   product on the matrix cores; the FP64 16x16x4 accumulator layout (lane l, register v <-> row 4v + (l>>4),
-//   column l&15) IS the B-operand fragment of k-step v, so each wave forms the QB of its own column tile in the
-//   registers that hold it for the whole pass (both Q sets: 128 VGPRs);
-// * row blocks of 16 stream through (P'A[I] and P'B[I] by LDS-DMA, double buffered: 4 x 16.6 KB), one 16 x 16
-//   tile per wave; between the two rank-64 phases the accumulators of B's pivot rows are cleared -- the sums stay
-//   in 3M form (s1, s2, s3) across both phases and are recombined once;
+// * both Q sets sit in registers for the whole pass (128 VGPRs); row blocks of 16 stream through (P''A[I] and P'B[I]
+//   by LDS-DMA, double buffered: 4 x 16.9 KB), one 16 x 16 tile per wave, 32 k-steps, sums in 3M form;
 // * addresses are 32-bit byte offsets from the wave-uniform matrix base, recomputed where they are used: with
 //   both Q sets in registers there is no room for loop-carried 64-bit pointers (n <= 8192: 16 n^2 < 2^32);
 // * software pipeline and XCD-aware launch order as in gj_colupdate_kernel.
 __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
     int n, int nb, cplx* __restrict__ bufA, size_t mat_stride, const int* __restrict__ piv_all, int c0, int cwB)
 {
-    __shared__ cplx As2[2][2][16 * CU_AP];        // [buffer][window A / B] P'[I], 16 rows  (66.5 KB)
-    __shared__ unsigned char pflag[8192];         // bit 0: pivot row of window A, bit 1: of window B
+    __shared__ cplx As2[2][2][16 * CU_AP];        // [buffer][window A / B] P[I], 16 rows
+    __shared__ unsigned char pflag[8192];         // row is a pivot row of window A or B (its old content counts as zero)
     const int nblk = (n + 63) >> 6, jwin = c0 >> 6, per_mat = nblk - 2, cB = c0 + 64;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int m = (slot / per_mat) * 8 + xcd;
@@ -1191,10 +1192,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
     const unsigned un = (unsigned)n;
     const unsigned a_lane = (unsigned)(c0 + lane), b_lane = (unsigned)(cB + min(lane, cwB - 1));
 
-    for (int i = tid; i < n; i += CU_THREADS) {
-        const int c = colof[i];
-        pflag[i] = (unsigned char)(((c >= c0 && c < cB) ? 1 : 0) | ((c >= cB && c < cB + cwB) ? 2 : 0));
-    }
+    for (int i = tid; i < n; i += CU_THREADS) { const int c = colof[i]; pflag[i] = (c >= c0 && c < cB + cwB) ? 1 : 0; }
     auto lds_dma_off = [&](unsigned byte_off, cplx* dst) __attribute__((always_inline)) {
         const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane(
             (int)(unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);     // wave-uniform -> SGPR
@@ -1202,45 +1200,16 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(byte_off), "s"(lds_dst), "s"(Wb) : "memory");
     };
-    // ---- QA in place; QB = W[pivB] + P'A[pivB] QA (all 64 rows of this wave's column tile)
+    // ---- QA, QB: the pivot rows of both windows in this wave's column tile, in place (read before the first store)
     cplx qfA[16], qfB[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        const cplx v = W[(size_t)pivrow[c0 + ks * 4 + fk] * n + colc];
-        qfA[ks] = cmake(col_ok ? v.x : 0.0, col_ok ? v.y : 0.0);
-    }
-    {
-        cplx* R0 = &As2[0][0][0];                  // [64][CU_AP]: P'A of B's pivot rows
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int k = wave * 16 + j;
-            lds_dma_off(((unsigned)pivrow[cB + min(k, cwB - 1)] * un + a_lane) * 16u, R0 + k * CU_AP);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks)             // qfB starts as the old content of B's pivot rows
-            qfB[ks] = W[(size_t)pivrow[cB + min(ks * 4 + fk, cwB - 1)] * n + colc];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const cplx* ab = R0 + fi * CU_AP + fk;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {               // virtual row tile a: k rows 16 a .. 16 a + 15 = k-steps 4 a .. 4 a + 3
-            d4 cr, ci, cs = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { cr[r] = qfB[a * 4 + r].x; ci[r] = qfB[a * 4 + r].x + qfB[a * 4 + r].y; }
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const cplx af = ab[a * 16 * CU_AP + ks * 4];
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x, qfA[ks].x, cr, 0, 0, 0);
-                cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af.y, qfA[ks].y, cs, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af.x + af.y, qfA[ks].x + qfA[ks].y, ci, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (a * 16 + 4 * r + fk < cwB) & col_ok;
-                qfB[a * 4 + r] = cmake(ok ? cr[r] - cs[r] : 0.0, ok ? ci[r] - cr[r] - cs[r] : 0.0);
-            }
-        }
-        __syncthreads();                           // the staging area is free for the pipeline's buffers
+        const int k = ks * 4 + fk;
+        const cplx va = W[(size_t)pivrow[c0 + k] * n + colc];
+        const cplx vb = W[(size_t)pivrow[cB + min(k, cwB - 1)] * n + colc];
+        const bool okb = (k < cwB) & col_ok;
+        qfA[ks] = cmake(col_ok ? va.x : 0.0, col_ok ? va.y : 0.0);
+        qfB[ks] = cmake(okb ? vb.x : 0.0, okb ? vb.y : 0.0);
     }
 
     const int nrb = (n + 15) >> 4;
@@ -1276,14 +1245,11 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
     for (int ib = 0; ib < nrb; ++ib) {
         const int buf = ib & 1;
         d4 cr, ci, cs = {0, 0, 0, 0};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of P'[ib] (not in hipcc's bookkeeping)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the LDS-DMA of P[ib] (not in hipcc's bookkeeping); the Q fragments
         __syncthreads();
-        unsigned fl = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned f = pflag[min(ib * 16 + fk + 4 * r, n - 1)];
-            fl |= f << (2 * r);
-            const bool z = (f & 1u) != 0;
+            const bool z = pflag[min(ib * 16 + fk + 4 * r, n - 1)] != 0;
             cr[r] = z ? 0.0 : cv[r].x; ci[r] = z ? 0.0 : cv[r].x + cv[r].y;
         }
         const cplx* abA = &As2[buf][0][fi * CU_AP + fk];
@@ -1304,11 +1270,6 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
             cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x, qfA[ks].x, cr, 0, 0, 0);
             cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].y, qfA[ks].y, cs, 0, 0, 0);
             ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x + af[cur].y, qs, ci, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool z = ((fl >> (2 * r)) & 2u) != 0;   // pivot row of B: its A-updated content was taken into QB
-            cr[r] = z ? 0.0 : cr[r]; cs[r] = z ? 0.0 : cs[r]; ci[r] = z ? 0.0 : ci[r];
         }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
@@ -1420,9 +1381,9 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
                 window(c0, cw);
                 colupdate(c0, cw, jA + 1);                        // A -> block B
                 window(cB, cwB);
+                colupdate(cB, cwB, jA);                           // B -> block A: the pair's transform is now [P''A | P'B]
                 hipLaunchKernelGGL(gj_colupdate2_kernel, dim3(8 * ((count + 7) / 8) * (nblk - 2)), dim3(CU_THREADS), 0, s,
                                    n, count, Ag, stride, (const int*)pg, c0, cwB);
-                colupdate(cB, cwB, jA);                           // B -> block A (P'A is no longer needed)
                 c0 += WIN;
                 continue;
             }
