@@ -531,9 +531,11 @@ int negf_set_system(negf_ctx* c, int n, const double* F, const double* S)
     }
     const cplx* Fh = reinterpret_cast<const cplx*>(F);
     const cplx* Sh = reinterpret_cast<const cplx*>(S);
-    // one of the systems already on the device?  (bitwise comparison with the host copies)
+    // one of the systems already on the device?  (bitwise comparison with the host copies; matrices above 256 MB
+    // -- n > 4096 -- keep one system only: a slot costs 2 x 16 n^2 bytes of HBM and of host memory)
+    const int nslots = n2 * sizeof(cplx) <= ((size_t)256 << 20) ? negf_ctx::NEGF_SYS_SLOTS : 1;
     int slot = -1;
-    for (int k = 0; k < negf_ctx::NEGF_SYS_SLOTS && slot < 0; ++k) {
+    for (int k = 0; k < nslots && slot < 0; ++k) {
         const auto& sl = c->sys[k];
         if (sl.valid && sl.hF.size() == n2 && std::memcmp(sl.hF.data(), Fh, n2 * sizeof(cplx)) == 0 &&
             std::memcmp(sl.hS.data(), Sh, n2 * sizeof(cplx)) == 0) slot = k;
@@ -542,7 +544,7 @@ int negf_set_system(negf_ctx* c, int n, const double* F, const double* S)
     if (slot < 0) {
         // least recently used slot (an empty one first)
         slot = 0;
-        for (int k = 1; k < negf_ctx::NEGF_SYS_SLOTS; ++k)
+        for (int k = 1; k < nslots; ++k)
             if (!c->sys[k].valid ? c->sys[slot].valid : (c->sys[slot].valid && c->sys[k].used < c->sys[slot].used)) slot = k;
         auto& sl = c->sys[slot];
         sl.valid = false;

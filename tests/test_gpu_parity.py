@@ -180,6 +180,44 @@ def test_workspace_is_stable_across_entry_points(engine):
         assert engine.get_batch() == b0
 
 
+def test_resident_systems_are_recognised_bitwise(engine):
+    """negf_set_system keeps the last two systems on the device and re-selects one it recognises bit for bit: alternating
+    between two systems (the spin blocks of a blockdiag Fock matrix), a third one evicting the least recently used, and a
+    matrix changed IN PLACE by the caller must each give the result of their own (F, S) -- with one constant provider
+    (whose F + Sigma_tot the library refreshes on every switch) serving all of them."""
+    from gaunegf_amd.integrate import GrInt
+    from gaunegf_amd.transport import SigmaCalculator, calculate_transmission
+    N = 40
+    systems = [random_system(N, 60 + k) for k in range(3)]
+    inds, s1, s2 = const_sigma_pair(N, systems[0][1], 4, 0.1)
+    sc = SigmaCalculator(s1, s2)
+    E = np.linspace(-1.0, 1.0, 9)
+    w = np.full(9, 0.25) + 0.0j
+
+    def ref_T(F, S):
+        out = []
+        for e in E:
+            G = np.linalg.inv(e * S - F - s1 - s2)
+            g1, g2 = 1j * (s1 - s1.conj().T), 1j * (s2 - s2.conj().T)
+            out.append(np.real(np.trace(g1 @ G @ g2 @ G.conj().T)))
+        return np.array(out)
+    for k in (0, 1, 0, 1, 2, 0, 1, 2, 2):
+        F, S = systems[k]
+        assert np.allclose(calculate_transmission(F, S, sc, E), ref_T(F, S), rtol=1e-9, atol=1e-12), k
+    F, S = systems[1]
+    before = calculate_transmission(F, S, sc, E)
+    F[3, 3] += 0.25                                     # the caller's array changes in place: a different system
+    after = calculate_transmission(F, S, sc, E)
+    assert np.allclose(after, ref_T(F, S), rtol=1e-9, atol=1e-12) and not np.allclose(after, before, rtol=1e-6)
+    # and through a provider object that carries its own constant self-energies
+    from gaunegf_amd.surfGTester import surfGTest
+    for k in (0, 2, 0):
+        F, S = systems[k]
+        g_dev = surfGTest(F, S, inds, -0.1j)
+        g_ref = oracle.ConstSigma(F, S, inds, -0.1j)
+        assert rel_fro(GrInt(F, S, g_dev, E + 0.05j, w), oracle.GrInt(F, S, g_ref, E + 0.05j, w)) < TOL, k
+
+
 @pytest.mark.parametrize("N", [2100, 4200])
 def test_largest_window_configurations(engine, N):
     """n > 2048 runs the windowed path with 8 rows per lane and sub-panels of 4 columns, n > 4096 with
