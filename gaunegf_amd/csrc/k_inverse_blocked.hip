@@ -691,7 +691,7 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
 
     const int fi = lane & 15, fk = lane >> 4;
     const int tiles = (n + 15) >> 4;
-    const int wt0 = c0 >> 4, wt1 = (c0 + cw + 15) >> 4;          // column tiles of the window
+    cplx* qwin2 = qwin + NBI * WIN;                              // Q of the second sub-panel of a pair
 
     int sti = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
@@ -699,11 +699,8 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
         ++sti;
     };
     stamp();
-    for (int k0 = c0; k0 < c0 + cw; k0 += NBI) {
-        const int kw = min(NBI, c0 + cw - k0);
-        __syncthreads();                 // previous window update (global stores) complete
-        stamp();                         // 1 + 5 s: sub-panel s starts
-        // ---- strips of the sub-panel, pivot steps (all 8 waves form the panel team)
+    // ---- strips of sub-panel [k0, k0 + kw) into registers, pivot steps (all 8 waves form the panel team), strips back
+    auto factor = [&](int k0, int kw) __attribute__((always_inline)) {
         cplx a[RPT][S];
         bool avail[RPT];
 #pragma unroll
@@ -717,9 +714,9 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
         }
         {
             // the slots were left at zero by the previous panel (every column resets the slot two ahead;
-        // the last two columns of a panel publish nothing into theirs)
-        PanelCtx<C> ctx{a, avail, cand, slot, &bad_sh, pivrow, colof,
-                                      &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, nullptr};
+            // the last two columns of a panel publish nothing into theirs)
+            PanelCtx<C> ctx{a, avail, cand, slot, &bad_sh, pivrow, colof,
+                            &team_ctr, team_expect, n, k0, kw, tid, lane, wave, 0, tid, nullptr};
             stamp();                     // strips loaded
             publish_candidate<C>(ctx, 0, 0, 0);
             team_sync<PW>(&team_ctr, team_expect, lane);
@@ -736,34 +733,41 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
                     if (s < kw) g[s] = a[q][s];
             }
         }
-        __syncthreads();                 // sub-panel columns and pivrow/colof (global) visible
-        stamp();                         // strips stored
-        // ---- pivot rows of this sub-panel, window columns -> LDS
+    };
+    // ---- pivot rows of sub-panel [k0, k0 + kw), window columns -> LDS
+    auto stage_q = [&](cplx* qdst, int k0, int kw) __attribute__((always_inline)) {
         for (int t = tid; t < NBI * WIN; t += PT) {
             const int k = t / WIN, j = t - k * WIN;
-            qwin[t] = (k < kw && c0 + j < n && j < cw) ? W[(size_t)pivrow[k0 + k] * n + c0 + j] : cmake(0.0, 0.0);
+            qdst[t] = (k < kw && c0 + j < n && j < cw) ? W[(size_t)pivrow[k0 + k] * n + c0 + j] : cmake(0.0, 0.0);
         }
-        __syncthreads();
-        stamp();                         // Q of the sub-panel staged
-        // ---- apply the sub-panel transform to the other window columns (in place).  A wave takes whole
-        // row tiles: the P operand (the sub-panel's columns of the 16 rows) and the rows' pivot flags are
-        // fetched once per row tile and serve all column tiles of the window; every load is issued up
-        // front on clamped addresses (selects afterwards, no branch between a load and its MFMA) -- the
-        // operands come from L2 / HBM, and a dependent chain of such loads per tile was what this phase
-        // spent its time on.
-        constexpr int WT = WIN / 16;                                 // column tiles of a full window
+    };
+    // ---- apply sub-panel a = [ka, ka + kwa) (Q rows in qa) and, with kwb > 0, sub-panel b as well to the window
+    // columns [clo, chi) minus the sub-panels' own columns, in place:
+    //     W[i][col] = (i pivot row of a or b ? 0 : W[i][col]) + Pa[i][:] Qa[:][col] (+ Pb[i][:] Qb[:][col])
+    // A wave takes whole row tiles: the P operands (the sub-panels' columns of the 16 rows) and the rows' pivot flags are
+    // fetched once per row tile and serve all column tiles; every load is issued up front on clamped addresses
+    // (selects afterwards, no branch between a load and its MFMA) -- the operands come from L2 / HBM, and a dependent
+    // chain of such loads per tile was what this phase spent its time on.
+    constexpr int WT = WIN / 16;                                     // column tiles of a full window
+    auto update = [&](int clo, int chi, int ka, int kwa, const cplx* qa, int kb, int kwb, const cplx* qb) __attribute__((always_inline)) {
+        const bool two = kwb > 0;                                    // (uniform)
+        const int t_lo = (clo - c0) >> 4, t_hi = (chi - c0 + 15) >> 4;
         for (int ti = wave; ti < tiles; ti += PW) {
             const int prow = min(ti * 16 + fi, n - 1);
-            cplx pa[KS];
+            cplx pa[KS], pb[KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) pa[ks] = W[(size_t)prow * n + min(k0 + ks * 4 + fk, n - 1)];   // k >= kw pairs with Q == 0
+            for (int ks = 0; ks < KS; ++ks) pa[ks] = W[(size_t)prow * n + min(ka + ks * 4 + fk, n - 1)];   // k >= kw pairs with Q == 0
+            if (two) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) pb[ks] = W[(size_t)prow * n + min(kb + ks * 4 + fk, n - 1)];
+            }
             bool keep[4];
             const cplx* crow[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = min(ti * 16 + fk + 4 * r, n - 1);
                 const int cf = colof[i];
-                keep[r] = !(cf >= k0 && cf < k0 + kw);
+                keep[r] = !(cf >= ka && cf < ka + kwa) && !(two && cf >= kb && cf < kb + kwb);
                 crow[r] = W + (size_t)i * n;
             }
             // the C tiles of all column tiles at once where the register strips leave room (<= 2 rows per
@@ -773,16 +777,19 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             if (CB == WT) {
 #pragma unroll
                 for (int t = 0; t < CB; ++t) {
-                    const int colc = min(c0 + t * 16 + fi, n - 1);
+                    if (t >= t_lo && t < t_hi) {                     // (uniform)
+                        const int colc = min(c0 + t * 16 + fi, n - 1);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cv[t][r] = crow[r][colc];
+                        for (int r = 0; r < 4; ++r) cv[t][r] = crow[r][colc];
+                    }
                 }
             }
 #pragma unroll
             for (int t = 0; t < WT; ++t) {
-                if (t < wt1 - wt0) {                                 // uniform: a narrow last window has fewer tiles
+                if (t >= t_lo && t < t_hi) {                         // (uniform)
                     const int col = c0 + t * 16 + fi;
-                    const bool col_store = col < n && col < c0 + cw && !(col >= k0 && col < k0 + kw);
+                    const bool col_store = col < n && col < c0 + cw && col >= clo && col < chi &&
+                                           !(col >= ka && col < ka + kwa) && !(two && col >= kb && col < kb + kwb);
                     if (CB == 1) {
                         const int colc = min(col, n - 1);
 #pragma unroll
@@ -798,11 +805,22 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
                     for (int ks = 0; ks < KS; ++ks) {
                         // (zero outside the sub-panel / window; sub-panels narrower than a k-step have no such row)
                         const int kq = ks * 4 + fk;
-                        cplx qb = qwin[(NBI % 4 == 0 ? kq : min(kq, NBI - 1)) * WIN + t * 16 + fi];
-                        if (NBI % 4 != 0 && kq >= NBI) qb = cmake(0.0, 0.0);
-                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, qb.x, accr, 0, 0, 0);
-                        accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, qb.y, accs, 0, 0, 0);
-                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x + pa[ks].y, qb.x + qb.y, acci, 0, 0, 0);
+                        cplx q = qa[(NBI % 4 == 0 ? kq : min(kq, NBI - 1)) * WIN + t * 16 + fi];
+                        if (NBI % 4 != 0 && kq >= NBI) q = cmake(0.0, 0.0);
+                        accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x, q.x, accr, 0, 0, 0);
+                        accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].y, q.y, accs, 0, 0, 0);
+                        acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[ks].x + pa[ks].y, q.x + q.y, acci, 0, 0, 0);
+                    }
+                    if (two) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const int kq = ks * 4 + fk;
+                            cplx q = qb[(NBI % 4 == 0 ? kq : min(kq, NBI - 1)) * WIN + t * 16 + fi];
+                            if (NBI % 4 != 0 && kq >= NBI) q = cmake(0.0, 0.0);
+                            accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[ks].x, q.x, accr, 0, 0, 0);
+                            accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[ks].y, q.y, accs, 0, 0, 0);
+                            acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[ks].x + pb[ks].y, q.x + q.y, acci, 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -812,6 +830,40 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
                 }
             }
         }
+    };
+    // Sub-panels in PAIRS (the same algebra as the window pairs of gj_colupdate2_kernel, one level down): sub-panel A is
+    // applied to the columns of B only, B is factored and applied to the columns of A (-> P''A), and the other columns of
+    // the window then take ONE rank-2*NBI update with [P''A | PB] and the RAW pivot rows of both -- the in-window update
+    // streams the n x 64 window block through at Infinity-Cache bandwidth, and this way a third less of it.
+    for (int k0 = c0; k0 < c0 + cw; ) {
+        const int kw = min(NBI, c0 + cw - k0);
+        const int k1 = k0 + NBI, kw1 = min(NBI, c0 + cw - k1);       // the second sub-panel of the pair (kw1 <= 0: none)
+        __syncthreads();                 // previous window update (global stores) complete
+        stamp();                         // 1 + 5 s: sub-panel s starts
+        factor(k0, kw);
+        __syncthreads();                 // sub-panel columns and pivrow/colof (global) visible
+        stamp();                         // strips stored
+        stage_q(qwin, k0, kw);
+        __syncthreads();
+        stamp();                         // Q of the sub-panel staged
+        if (kw1 <= 0) {                  // a lone last sub-panel reaches all other window columns
+            update(c0, c0 + cw, k0, kw, qwin, 0, 0, qwin);
+            k0 += NBI;
+            continue;
+        }
+        update(k1, k1 + kw1, k0, kw, qwin, 0, 0, qwin);              // A -> the columns of B
+        __syncthreads();
+        stamp();
+        factor(k1, kw1);
+        __syncthreads();
+        stamp();
+        stage_q(qwin2, k1, kw1);
+        __syncthreads();
+        stamp();
+        update(k0, k0 + kw, k1, kw1, qwin2, 0, 0, qwin2);            // B -> the columns of A: P''A
+        __syncthreads();                 // P''A complete before any wave reads it as an operand
+        update(c0, c0 + cw, k0, kw, qwin, k1, kw1, qwin2);           // everything else: one pass, both sub-panels
+        k0 += 2 * NBI;
     }
     stamp();                             // thread 0's share of the last update done
     __syncthreads();
@@ -1316,7 +1368,7 @@ template <int NBI, int RPT>
 void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
 {
     using C = GjCfg<NBI, 1, RPT, PW, PW>;
-    const size_t smem = (size_t)(2 * PW * NBI + NBI * WIN) * sizeof(cplx);
+    const size_t smem = (size_t)(2 * PW * NBI + 2 * NBI * WIN) * sizeof(cplx);      // candidate rows + Q of two sub-panels
     auto kern = gj_window_kernel<NBI, RPT>;
     static bool attr_set = false;
     if (!attr_set) {
