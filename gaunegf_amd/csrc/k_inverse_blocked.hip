@@ -831,6 +831,65 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             }
         }
     };
+    // ---- the same for ONE column tile (the two single-tile updates of a pair: A -> the columns of B, B -> the columns
+    // of A).  With one 16 x 16 tile per row tile the loop above is a chain of memory round trips (28 us for 63 row
+    // tiles at n = 1000 against 74 us for the fused pass over two tiles): here the operands of the wave's NEXT row tile
+    // are requested before the current one runs its matrix instructions.
+    auto update_one = [&](int clo, int chi, int ka, int kwa, const cplx* qa) __attribute__((always_inline)) {
+        const int t = (clo - c0) >> 4;                               // the tile that holds [clo, chi)
+        const int col = c0 + t * 16 + fi;
+        const int colc = min(col, n - 1);
+        const bool col_store = col < n && col < c0 + cw && col >= clo && col < chi && !(col >= ka && col < ka + kwa);
+        cplx q[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kq = ks * 4 + fk;
+            q[ks] = qa[(NBI % 4 == 0 ? kq : min(kq, NBI - 1)) * WIN + t * 16 + fi];
+            if (NBI % 4 != 0 && kq >= NBI) q[ks] = cmake(0.0, 0.0);
+        }
+        cplx pa[2][KS], cv[2][4];
+        int cf[2][4];
+        auto fetch = [&](int ti, int b) __attribute__((always_inline)) {
+            const int prow = min(ti * 16 + fi, n - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pa[b][ks] = W[(size_t)prow * n + min(ka + ks * 4 + fk, n - 1)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = min(ti * 16 + fk + 4 * r, n - 1);
+                cf[b][r] = colof[i];
+                cv[b][r] = W[(size_t)i * n + colc];
+            }
+        };
+        auto compute = [&](int ti, auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            d4 accr, acci, accs = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool keep = !(cf[b][r] >= ka && cf[b][r] < ka + kwa);
+                accr[r] = keep ? cv[b][r].x : 0.0; acci[r] = keep ? cv[b][r].x + cv[b][r].y : 0.0;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[b][ks].x, q[ks].x, accr, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[b][ks].y, q[ks].y, accs, 0, 0, 0);
+                acci = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[b][ks].x + pa[b][ks].y, q[ks].x + q[ks].y, acci, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ti * 16 + fk + 4 * r;
+                if (i < n && col_store) W[(size_t)i * n + col] = cmake(accr[r] - accs[r], acci[r] - accr[r] - accs[r]);
+            }
+        };
+        if (wave < tiles) fetch(wave, 0);
+        for (int ti = wave; ti < tiles; ti += 2 * PW) {             // two row tiles per trip: the buffers are indexed statically
+            if (ti + PW < tiles) fetch(ti + PW, 1);
+            compute(ti, std::integral_constant<int, 0>());
+            if (ti + PW < tiles) {
+                if (ti + 2 * PW < tiles) fetch(ti + 2 * PW, 0);
+                compute(ti + PW, std::integral_constant<int, 1>());
+            }
+        }
+    };
     // Sub-panels in PAIRS (the same algebra as the window pairs of gj_colupdate2_kernel, one level down): sub-panel A is
     // applied to the columns of B only, B is factored and applied to the columns of A (-> P''A), and the other columns of
     // the window then take ONE rank-2*NBI update with [P''A | PB] and the RAW pivot rows of both -- the in-window update
@@ -851,7 +910,10 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
             k0 += NBI;
             continue;
         }
-        update(k1, k1 + kw1, k0, kw, qwin, 0, 0, qwin);              // A -> the columns of B
+        // (sub-panels of 16 -- the 256-VGPR instantiations with two row strips per lane -- spill into their pivot steps
+        //  with the pipelined form: n = 800 83.9 -> 85.1 ms; the narrower ones gain: n = 2000 312 -> 296 ms)
+        if constexpr (NBI < 16) update_one(k1, k1 + kw1, k0, kw, qwin);    // A -> the columns of B
+        else update(k1, k1 + kw1, k0, kw, qwin, 0, 0, qwin);
         __syncthreads();
         stamp();
         factor(k1, kw1);
@@ -860,7 +922,8 @@ __global__ __launch_bounds__(PT) void gj_window_kernel(
         stage_q(qwin2, k1, kw1);
         __syncthreads();
         stamp();
-        update(k0, k0 + kw, k1, kw1, qwin2, 0, 0, qwin2);            // B -> the columns of A: P''A
+        if constexpr (NBI < 16) update_one(k0, k0 + kw, k1, kw1, qwin2);   // B -> the columns of A: P''A
+        else update(k0, k0 + kw, k1, kw1, qwin2, 0, 0, qwin2);
         __syncthreads();                 // P''A complete before any wave reads it as an operand
         update(c0, c0 + cw, k0, kw, qwin, k1, kw1, qwin2);           // everything else: one pass, both sub-panels
         k0 += 2 * NBI;
