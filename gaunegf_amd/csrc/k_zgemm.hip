@@ -30,11 +30,49 @@ static constexpr int ZG_BM = 64, ZG_BN = 64, ZG_BK = 16;
 static constexpr int ZG_APITCH = ZG_BK + 1;     // odd pitch: 16 rows -> 16 distinct 16-B slots
 static constexpr int ZG_BPITCH = ZG_BN + 1;
 
+// Hermitian form: the 1-D grid enumerates the upper triangle of the T x T block tiles of nb matrices so that the XCDs
+// (workgroup index mod 8) get equal shares AND whole block columns: columns c and T-1-c form a pair of c+1 and T-c =
+// T+1 blocks, pair gp = z * P + p (P = ceil(T/2) pairs per matrix) goes to XCD gp mod 8, and an XCD walks down a pair's
+// blocks in turn -- the B operand of a block column stays in that XCD's L2.  the batch size comes as a kernel argument (blockIdx.z is 0);
+// (x, y) of a full T x T grid with the lower blocks returning at once loaded the XCDs unevenly: slower than the full product.
+__device__ __forceinline__ bool zg_herm_decode(int T, int nb, int L, int* by, int* bx, int* b)
+{
+    if (T & 1) {
+        // an odd number of block columns leaves the middle one without a partner (half a pair's work: XCDs 2 : 1 at
+        // T = 3); there the triangle is simply enumerated row by row, matrix after matrix
+        const int ntri = T * (T + 1) / 2;
+        const int z = L / ntri;
+        int t = L - z * ntri, y = 0;
+        if (z >= nb) return false;
+        while (t >= T - y) { t -= T - y; ++y; }
+        *by = y; *bx = y + t; *b = z;
+        return true;
+    }
+    const int P = (T + 1) >> 1;
+    const int xcd = L & 7, slot = L >> 3;
+    const int q = slot / (T + 1), r = slot - q * (T + 1);
+    const int gp = xcd + 8 * q;
+    const int z = gp / P, p = gp - z * P;
+    if (z >= nb) return false;
+    const int c1 = p, c2 = T - 1 - p;
+    if (r <= c1) { *by = r; *bx = c1; }
+    else if (c1 != c2) { *by = r - (c1 + 1); *bx = c2; }
+    else return false;
+    *b = z;
+    return true;
+}
+static inline unsigned zg_herm_grid(long T, long nb)
+{
+    if (T & 1) return (unsigned)(T * (T + 1) / 2 * nb);
+    const long P = (T + 1) / 2;
+    return (unsigned)(8 * ((P * nb + 7) / 8) * (T + 1));
+}
+
 __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
     int M, int N, int K,
     const cplx* __restrict__ Aall, int lda, size_t strideA,
     const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB_arg,
-    cplx* __restrict__ Call, int ldc, size_t strideC)
+    cplx* __restrict__ Call, int ldc, size_t strideC, int nbatch)
 {
     __shared__ cplx As[ZG_BM * ZG_APITCH];      // As[i][k]
     __shared__ cplx Bs[ZG_BK * ZG_BPITCH];      // Bs[k][j]  (already op()'ed)
@@ -44,15 +82,9 @@ __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
     // Hermitian form: the grid is the upper triangle itself, row by row (gridDim.x = T (T + 1) / 2 block tiles) -- a
     // full T x T grid with the lower blocks returning at once loads the XCDs (block index mod 8) unevenly and ran
     // SLOWER than the full product (n = 1000: 67 ms against 52)
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (herm) {
-        const int T = (N + ZG_BN - 1) / ZG_BN;
-        int t = blockIdx.x; by = 0;
-        while (t >= T - by) { t -= T - by; ++by; }
-        bx = by + t;
-    }
+    int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
+    if (herm && !zg_herm_decode((N + ZG_BN - 1) / ZG_BN, nbatch, (int)blockIdx.x, &by, &bx, &b)) return;
     const bool mirror = herm && by < bx;
-    const int b = blockIdx.z;
     const cplx* A = Aall + (size_t)b * strideA;
     const cplx* B = Ball + (size_t)b * strideB;
     cplx* C = Call + (size_t)b * strideC;
@@ -205,21 +237,16 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
     int M, int N, int K, int nbm, int nbn,
     const cplx* __restrict__ Aall, int lda, size_t strideA,
     const cplx* __restrict__ Ball, int ldb, size_t strideB, int opB_arg,
-    cplx* __restrict__ Call, int ldc, size_t strideC)
+    cplx* __restrict__ Call, int ldc, size_t strideC, int nbatch)
 {
     __shared__ cplx As[ZF_ROWS * ZF_APITCH];     // As[i][k]
     __shared__ cplx Bs[ZG_BK * ZF_BPITCH];       // Bs[k][j]  (already op()'ed)
     __shared__ cplx Ts[ZF_WAVES * 16 * 17];      // per-wave transpose patch of the Hermitian mirror image
     const bool herm = (opB_arg & 2) != 0;        // see zgemm_mfma_kernel (M == N: the row and column blocks coincide)
     const int opB = opB_arg & 1;
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (herm) {                                  // the grid is the upper triangle of the nbn x nbn blocks, row by row
-        int t = blockIdx.x; by = 0;
-        while (t >= nbn - by) { t -= nbn - by; ++by; }
-        bx = by + t;
-    }
+    int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
+    if (herm && !zg_herm_decode(nbn, nbatch, (int)blockIdx.x, &by, &bx, &b)) return;
     const bool mirror = herm && by < bx;
-    const int b = blockIdx.z;
     const cplx* A = Aall + (size_t)b * strideA;
     const cplx* B = Ball + (size_t)b * strideB;
     cplx* C = Call + (size_t)b * strideC;
@@ -412,14 +439,14 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
         if (flex_env == 2 || (flex_env == 1 && padded)) {
             const int nbm = (int)((tm16 + ZF_MAXT - 1) / ZF_MAXT), nbn = (int)((tn16 + ZF_MAXT - 1) / ZF_MAXT);
             dim3 grid(nbn, nbm, nb);
-            if (opB & 2) grid = dim3(nbn * (nbn + 1) / 2, 1, nb);
+            if (opB & 2) grid = dim3(zg_herm_grid(nbn, nb), 1, 1);
             hipLaunchKernelGGL(zgemm_flex_kernel, grid, dim3(ZF_THREADS), 0, st, M, N, K, nbm, nbn, A, lda, strideA,
-                               B, ldb, strideB, opB, C, ldc, strideC);
+                               B, ldb, strideB, opB, C, ldc, strideC, nb);
         } else {
             dim3 grid((unsigned)bn64, (unsigned)bm64, nb);
-            if (opB & 2) grid = dim3((unsigned)(bn64 * (bn64 + 1) / 2), 1, nb);
+            if (opB & 2) grid = dim3(zg_herm_grid(bn64, nb), 1, 1);
             hipLaunchKernelGGL(zgemm_mfma_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,
-                               strideB, opB, C, ldc, strideC);
+                               strideB, opB, C, ldc, strideC, nb);
         }
     }
 }
