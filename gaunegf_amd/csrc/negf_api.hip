@@ -932,12 +932,14 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
         if (spin_mode == NEGF_SPIN_RESTRICTED) {
             {
                 ProfScope ps(c, "zgemm");
-                // X = Gamma_L G ; Y = X Gamma_R ; T = Re sum Y_ij conj(G_ij)  (transport.py:156-157)
-                launch_zgemm(c->stream, n, n, n, nb, gamL, n, gsL, G, n, n2, 0, X, n, n2);
-                launch_zgemm(c->stream, n, n, n, nb, X, n, n2, gamR, n, gsR, 0, Y, n, n2);
+                // T = Re Tr[Gamma_L G Gamma_R G^H]  (transport.py:156-157) as  X = G Gamma_R ;  M = X G^H -- Hermitian,
+                // as Gamma_R is: upper block tiles only (launch_zgemm opB = 3) -- ;  T = Re sum Gamma_L,ij conj(M_ij)
+                // ( = Re Tr[Gamma_L M], M_ji = conj(M_ij)): one and a half dense products instead of two
+                launch_zgemm(c->stream, n, n, n, nb, G, n, n2, gamR, n, gsR, 0, X, n, n2);
+                launch_zgemm(c->stream, n, n, n, nb, X, n, n2, G, n, n2, 3, Y, n, n2);
             }
             ProfScope ps(c, "trace");
-            launch_trace_dot(c->stream, n, n, nb, Y, n, n2, G, n, n2, T_dev + m0, 1);
+            launch_trace_dot(c->stream, n, n, nb, gamL, n, gsL, Y, n, n2, T_dev + m0, 1);
         } else {
             const int h = n / 2;
             // blocks [uu, ud, du, dd]: G rows/cols offsets; Gamma_L blocks [uu,uu,dd,dd];
