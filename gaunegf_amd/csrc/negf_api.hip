@@ -860,7 +860,9 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
             launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, gam, n, gs, 0, c->W2, n, n2);
             // (G Gamma G^H is Hermitian -- Gamma = i (Sigma - Sigma^H) is, element by element -- : upper block tiles
             //  computed, lower ones mirrored)
-            launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, 3, c->W1, n, n2);
+            // (coupling matrices handed in by the caller -- pre_is_gamma -- need not be Hermitian: the full product)
+            launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2,
+                         (p->kind == SK_PRECOMPUTED && p->pre_is_gamma) ? 1 : 3, c->W1, n, n2);
         }
         ProfScope ps(c, "accumulate");
         launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);
@@ -935,8 +937,14 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
                 // T = Re Tr[Gamma_L G Gamma_R G^H]  (transport.py:156-157) as  X = G Gamma_R ;  M = X G^H -- Hermitian,
                 // as Gamma_R is: upper block tiles only (launch_zgemm opB = 3) -- ;  T = Re sum Gamma_L,ij conj(M_ij)
                 // ( = Re Tr[Gamma_L M], M_ji = conj(M_ij)): one and a half dense products instead of two
+                // (explicit Gamma matrices handed in by the caller -- negf_sigma_precomputed with gammas, the
+                //  reference's _transmission_kernel_restricted(E, F, S, sigma, gamma1, gamma2) -- need not be
+                //  Hermitian: M is then computed in full, opB = 1, and T = Re Tr[Gamma_L M] = Re sum Gamma_L,ij M_ji
+                //  is taken with M^H: sum Re(Gamma_L,ij conj(M^H_ij)))
+                const bool herm_ok = !(p->kind == SK_PRECOMPUTED && p->pre_is_gamma);
                 launch_zgemm(c->stream, n, n, n, nb, G, n, n2, gamR, n, gsR, 0, X, n, n2);
-                launch_zgemm(c->stream, n, n, n, nb, X, n, n2, G, n, n2, 3, Y, n, n2);
+                if (herm_ok) launch_zgemm(c->stream, n, n, n, nb, X, n, n2, G, n, n2, 3, Y, n, n2);   // Y = M = X G^H
+                else launch_zgemm(c->stream, n, n, n, nb, G, n, n2, X, n, n2, 1, Y, n, n2);           // Y = G X^H = M^H
             }
             ProfScope ps(c, "trace");
             launch_trace_dot(c->stream, n, n, nb, gamL, n, gsL, Y, n, n2, T_dev + m0, 1);

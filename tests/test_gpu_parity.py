@@ -180,6 +180,27 @@ def test_workspace_is_stable_across_entry_points(engine):
         assert engine.get_batch() == b0
 
 
+def test_explicit_gammas_need_not_be_hermitian(engine):
+    """The per-energy kernels take the coupling matrices as arguments (transport.py:150-157): T = Re Tr[g1 G g2 G^H] for
+    ANY g1, g2.  The library computes G g2 G^H as a Hermitian product only for coupling matrices it formed itself
+    (Gamma = i (Sigma - Sigma^H)); matrices handed in by the caller take the full product."""
+    from gaunegf_amd.transport import _transmission_kernel_restricted
+    N = 70                                              # two block tiles of 64: an upper and a lower block exist
+    F, S = random_system(N, 91)
+    rng = np.random.default_rng(5)
+    sig = -0.05j * np.eye(N)
+    for herm in (True, False):
+        g1 = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        g2 = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        if herm:
+            g1, g2 = g1 + g1.conj().T, g2 + g2.conj().T
+        E = 0.3
+        G = np.linalg.inv(E * S - F - sig)
+        ref = np.real(np.trace(g1 @ G @ g2 @ G.conj().T))
+        got = _transmission_kernel_restricted(E, F, S, sig, g1, g2)
+        assert abs(got - ref) <= 1e-9 * max(1.0, abs(ref)), (herm, got, ref)
+
+
 def test_resident_systems_are_recognised_bitwise(engine):
     """negf_set_system keeps the last two systems on the device and re-selects one it recognises bit for bit: alternating
     between two systems (the spin blocks of a blockdiag Fock matrix), a third one evicting the least recently used, and a
