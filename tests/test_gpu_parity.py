@@ -83,6 +83,27 @@ def test_windowed_inverse_batch_shapes(engine, N, M):
         assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9, (N, M, k)
 
 
+def test_blocked_inverses_random_shapes(engine):
+    """Seeded random dimensions and batch sizes through the blocked inverses (the round-3 fuzz of scripts/fuzz_inverse.py in
+    small): odd window counts, last windows and sub-panels of any width, batches on either side of the eight-wave / lean
+    update selection; every sampled matrix checked by its residual."""
+    from gaunegf_amd.integrate import GrBatch
+    from gaunegf_amd.surfGTester import surfGTest
+    rng = np.random.default_rng(2026)
+    cases = [(int(rng.integers(257, 700)), int(rng.integers(1, 40))) for _ in range(7)]
+    cases += [(int(rng.integers(33, 257)), int(rng.integers(1, 60))) for _ in range(3)] + [(int(rng.integers(1025, 1200)), 2)]
+    for n, m in cases:
+        F, S = random_system(n, int(rng.integers(1 << 30)))
+        nc = max(2, n // 20)
+        g = surfGTest(F, S, [list(range(nc)), list(range(n - nc, n))], -0.1j)
+        E = np.linspace(-2.0, 2.0, m) + 0.02j
+        G = GrBatch(F, S, g, E)
+        sig = g.sigmaTot(0.0)
+        for k in sorted({0, m // 2, m - 1}):
+            A = E[k] * S - F - sig
+            assert np.linalg.norm(G[k] @ A - np.eye(n)) / np.sqrt(n) < 1e-9, (n, m, k)
+
+
 @pytest.mark.parametrize("N,M", [(300, 480), (449, 640)])
 def test_windowed_inverse_large_batches(engine, N, M):
     """Batches large enough for the throughput configuration of the windowed inverse: four stream groups of >= 120
