@@ -82,7 +82,7 @@ void free_provider(SigmaProvider* p)
     dev_free(p->d_tau); dev_free(p->d_Stau); dev_free(p->d_lead_pad);
     dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
     dev_free(p->d_H); dev_free(p->d_Slist); dev_free(p->d_Vlist); dev_free(p->d_xi);
-    dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order);
+    dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order); dev_free(p->d_prevE); dev_free(p->d_prev_iters);
     delete p;
 }
 
@@ -227,22 +227,39 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                 if (rc) return rc;
                 c->scratch_cap = need;
             }
-            // jobs in the order of decreasing sweep counts of the previous evaluation of a grid of this size
-            // (Fermi searches and SCF cycles evaluate the same grids over and over); afterwards the order
-            // for the next evaluation is derived from this one's counts, on the stream, without a host sync
+            // jobs in the order of decreasing sweep counts: the counts are predicted from the previous evaluation of
+            // this provider -- for each energy the count of the nearest energy evaluated then (Fermi searches and SCF
+            // cycles evaluate the same or slightly moved grids over and over; the same grid gets exactly its learned
+            // order) -- and sorted on the device, no host sync; the first evaluation runs in launch order
             const int jobs = nb * p->n_contacts;
             const bool can_order = p->force_iters < 0 && iters && chain1d_order_supported(jobs);
-            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch,
-                               (can_order && p->order_n == jobs) ? p->d_order : nullptr);
+            const int* order = nullptr;
             if (can_order) {
                 if (jobs > p->order_cap) {
                     NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
-                    dev_free(p->d_order); p->order_cap = 0; p->order_n = 0;
+                    dev_free(p->d_order); p->order_cap = 0;
                     int rc = dev_alloc(&p->d_order, (size_t)jobs);
                     if (rc) return rc;
                     p->order_cap = jobs;
                 }
-                launch_chain1d_order(c->stream, iters, jobs, p->d_order);
+                if (p->prev_n > 0) {
+                    launch_chain1d_predict_order(c->stream, p->d_prevE, p->d_prev_iters, p->prev_n, p->n_contacts, E, nb, p->d_order);
+                    order = p->d_order;
+                }
+            }
+            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, order);
+            if (can_order) {
+                // keep this evaluation's energies and counts for the next prediction
+                if (nb > p->prev_cap) {
+                    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+                    dev_free(p->d_prevE); dev_free(p->d_prev_iters); p->prev_cap = 0; p->prev_n = 0;
+                    int rc;
+                    if ((rc = dev_alloc(&p->d_prevE, (size_t)nb)) || (rc = dev_alloc(&p->d_prev_iters, (size_t)nb * p->n_contacts))) return rc;
+                    p->prev_cap = nb;
+                }
+                NEGF_HIP_CHECK(hipMemcpyAsync(p->d_prevE, E, (size_t)nb * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream));
+                NEGF_HIP_CHECK(hipMemcpyAsync(p->d_prev_iters, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                p->prev_n = nb;
                 p->order_n = jobs;
             }
             return NEGF_OK;

@@ -92,6 +92,10 @@ struct SigmaProvider {
     // job order learned from the previous evaluation of a grid of order_n jobs (chain kernel)
     int* d_order = nullptr;
     int order_n = 0, order_cap = 0;
+    // energies and sweep counts of the previous evaluation: the order of a NEW grid is predicted from them
+    cplx* d_prevE = nullptr;
+    int* d_prev_iters = nullptr;
+    int prev_n = 0, prev_cap = 0;
     // BETHE
     std::vector<int> n_atoms;      // atoms per contact
     int* d_atom_orbs = nullptr;    // [total_atoms][9]
@@ -247,6 +251,8 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
 // order[0..count) = jobs by decreasing sweep count of the evaluation that just ran (iters[count])
 bool chain1d_order_supported(int count);
 void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order);
+void launch_chain1d_predict_order(hipStream_t st, const cplx* prevE, const int* prev_iters, int prev_n, int n_contacts,
+                                  const cplx* E, int nb, int* order);
 
 // Bethe lattice: one workgroup per (energy, contact); writes per-atom 9x9 blocks
 void launch_bethe(hipStream_t st, const SigmaProvider& p, int nb, const cplx* E, cplx* blk,

@@ -543,6 +543,24 @@ def test_chain1d_free_running(engine):
     assert rel_fro(GrInt(F, S, g_dev, E, w), oracle.GrInt(F, S, g_ref, E, w)) < 1e-3
 
 
+def test_chain1d_order_predicted_for_new_grids(engine):
+    """The chain kernel starts its jobs longest first; the lengths are predicted from the previous evaluation of the
+    provider, for each energy the count of the nearest energy evaluated then -- also when the new grid has another size
+    (an adaptive grid doubling, a Fermi search moving its contour).  The launch order must never change a result: every
+    grid gives Sigma, the sweep counts and the convergence flags of a fresh provider's first (launch-order) evaluation,
+    bit for bit."""
+    nc = 10
+    grids = [np.linspace(-1.5, 1.5, 37), np.linspace(-1.4, 1.6, 64), np.linspace(-1.5, 1.5, 37) + 0.01,
+             np.linspace(-0.2, 0.2, 5), np.linspace(-1.5, 1.5, 37), np.linspace(-1.6, 1.4, 130) + 0.05j]
+    _, _, g_seq, _ = _chain_system(3 * nc, nc, 77, 1e-3)
+    for E in grids:
+        _, _, g_fresh, _ = _chain_system(3 * nc, nc, 77, 1e-3)
+        sig0, it0, cv0 = g_fresh.sigma_batch(E)                 # first evaluation of a provider: launch order
+        sig1, it1, cv1 = g_seq.sigma_batch(E)                   # order predicted from the grid before
+        assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
+        assert it1.max() > it1.min()                            # (the jobs do differ in length)
+
+
 @pytest.mark.parametrize("nc,eta", [(50, 1e-4), (64, 1e-3), (72, 1e-3)])
 def test_chain1d_free_running_large_leads(engine, nc, eta):
     """The reference's stopping rule (surfG1D.py:271-288) at BASELINE C3's lead size and at the two
