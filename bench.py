@@ -31,11 +31,18 @@ The default (c3) is the headline and the only configuration with CPU / secondary
 
 The JSON line carries
   roofline     : the kernel that dominates the step (the chain fixed point, > 90 % of it) against the
-                 FP64 matrix-core peak.  achieved = algorithmic flops per launch / average launch
-                 duration; flops per (energy, contact) = (8 + 24 sweeps + 16) n_c^3 (start inverse, per
-                 sweep an inverse and two products, Sigma = t g t^H), with the
-                 sweep counts the kernel reports; durations from hipEvents recorded by the library on
-                 the stream the kernels run on, during the timed steps.
+                 FP64 matrix-core peak, TWO ways, everywhere with the same meaning:
+                   achieved / frac_algorithmic -- ALGORITHMIC flops per launch / average launch duration; flops per
+                     (energy, contact) = (8 + 24 sweeps + 16) n_c^3 (start inverse, per sweep an inverse and two
+                     products, Sigma = t g t^H; 8 flop per complex multiply-add), with the sweep
+                     counts the kernel reports; durations from hipEvents recorded by the library on the stream the
+                     kernels run on, during the timed steps;
+                   mfma_executed / frac -- the flops actually ISSUED to the matrix cores / the same duration / the
+                     peak: the kernels form a complex product from three real ones (6 instead of 8 flop per complex
+                     multiply-add) on 16-granular tiles (padding counts, the pivot steps' vector work does not).
+                     frac <= 1 is asserted; only this one is a matrix-core utilisation.
+                 mfma_busy_frac is the PMC counter SQ_VALU_MFMA_BUSY_CYCLES of the committed profile of the same
+                 kernel source / (launch duration x 2.4 GHz x 1024 SIMDs).
   cpu_baseline : the numpy oracle (the reference's CPU restatement) timed on this host on a bounded
                  sample of the same energies.
   extra        : the north-star target case (N_orb = 500, constant Sigma, 1000 energies: GPU time and
@@ -57,6 +64,37 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X dense FP64 matrix peak (vector FP64 peak is the same)
+PEAK_CLOCK_HZ, N_SIMD = 2.4e9, 1024   # what the 78.6 TF are made of: 2048 flop / 64 cycles / SIMD
+
+
+def chain_mfma_flops_per_sweep(nc):
+    """Flops one sweep of chain1d_rs_kernel ISSUES to the matrix cores for an n_c-orbital lead (k_chain1d_rs.hip): two
+    products and the rank-8 trailing updates of the blocked inverse, in the 3M form when the lead spans three tiles or
+    more (else four real products), on 16 x 16 tiles; a last tile of <= 4 rows / columns runs as strips on the 4x4x4
+    instruction (a quarter of a tile's flops).  A model of the instruction stream (it ignores the half-tile updates
+    that compute a whole tile: a few per cent); the PMC counter behind mfma_busy_frac is the measurement."""
+    T = -(-nc // 16)
+    rem = T >= 2 and nc - 16 * (T - 1) <= 4
+    FT = T - 1 if rem else T
+    m = 3.0 if T >= 3 else 4.0
+    full, strip = 2048.0, 512.0
+    ks = -(-nc // 4)
+    # one product: every wave but the strip wave runs FT full tiles (+ one strip), the strip wave T strips, per k-step
+    waves_full = 3 if rem else 4
+    product = ks * m * (waves_full * (FT * full + (strip if rem else 0.0)) + ((T * strip) if rem else 0.0))
+    # inverse: panels of 8 columns, each applied to the T x T tiles with two k-steps (one when <= 4 columns remain)
+    tiles = FT * FT * full + ((2 * FT + 1) * strip if rem else 0.0)
+    inverse = sum((1 if min(8, nc - p0) <= 4 else 2) * m * tiles for p0 in range(0, nc, 8))
+    return 2.0 * product + inverse
+
+
+def roofline_pair(flops_alg, flops_mfma, seconds):
+    """The two fractions every roofline object of this file carries (see the module docstring)."""
+    tf_a = flops_alg / seconds / 1e12 if seconds > 0 else 0.0
+    tf_m = flops_mfma / seconds / 1e12 if seconds > 0 else 0.0
+    frac = tf_m / FP64_MFMA_PEAK_TFLOPS
+    assert frac <= 1.0, f"executed MFMA fraction {frac} above 1: the flop accounting is wrong"
+    return {"achieved": tf_a, "frac_algorithmic": tf_a / FP64_MFMA_PEAK_TFLOPS, "mfma_executed": tf_m, "frac": frac}
 
 
 # ------------------------------------------------------------------ synthetic systems (SURVEY 8d)
@@ -182,7 +220,17 @@ def cpu_baseline_pool(kind, payload, E, w, n_sample, label, workers=None):
     idx = np.linspace(0, E.size - 1, min(n_sample, E.size)).astype(int)
     chunks = [(E[c], w[c]) for c in np.array_split(idx, min(len(idx), workers * 4)) if len(c)]
     ctx = mp.get_context("spawn")                        # never fork a process that has initialised the GPU
-    with ctx.Pool(workers, initializer=_pool_init, initargs=(kind, payload)) as pool:
+    # one BLAS thread per worker, from the worker's first import on (a pool of 256 processes must not start 256
+    # BLAS thread pools of 256 threads each): the children inherit the environment of the moment they are spawned
+    keys = ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in keys}
+    os.environ.update({k: "1" for k in keys})
+    try:
+        pool = ctx.Pool(workers, initializer=_pool_init, initargs=(kind, payload))
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    with pool:
         pool.map(_pool_chunk, chunks[:workers])          # warm-up: imports, first BLAS calls
         t0 = time.perf_counter()
         parts = pool.map(_pool_chunk, chunks, chunksize=1)
@@ -226,6 +274,24 @@ def pmc_traffic_bytes(kernel_substr, source_file="k_chain1d_rs.hip"):
                     return (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0, os.path.join("profiles", fname)
                 reason = f"profiles/{fname} was taken on another version of {source_file}"
     return None, reason
+
+
+def pmc_counter(kernel_substr, counter, source_file="k_chain1d_rs.hip"):
+    """A per-launch counter of the committed PMC profile taken on the tree's version of `source_file`, or None."""
+    want = kernel_source_id(source_file)
+    for fname in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (fname.endswith(".json") and "pmc" in fname):
+            continue
+        try:
+            data = json.load(open(os.path.join(ROOT, "profiles", fname)))
+        except Exception:
+            continue
+        if want is None or data.get("_kernel_source_sha16", {}).get(source_file) != want:
+            continue
+        for name, ctr in data.items():
+            if isinstance(ctr, dict) and kernel_substr in name and counter in ctr:
+                return ctr[counter]
+    return None
 
 
 # ---------------------------------------------------------------------------------- the worker
@@ -272,6 +338,9 @@ def worker_c3(args):
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     eng.set_system(F, S)
+    # the headline is COLD: every step runs all fixed points.  (The context's g(E) cache -- negf_set_chain_cache --
+    # would serve steps 2.. from the surface Green's functions of step 1; that figure is reported separately below.)
+    eng.set_chain_cache(0)
     lead = surfG(F, S, inds, **kw)
     h = lead._negf_lower(eng)
     dev = torch.device("cuda", local_rank)
@@ -280,13 +349,20 @@ def worker_c3(args):
     out = torch.zeros((N, N), dtype=torch.complex128, device=dev)
     out_real = torch.view_as_real(out)
 
-    def step():
+    comm_events = []
+
+    def step(timed=False):
         eng.gr_int_dev(h, M, E_dev.data_ptr(), w_dev.data_ptr(), out.data_ptr())
         if world > 1:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
+            if ev:
+                ev[0].record(stream)
             if rehearsal:
                 t = out_real.cpu(); dist.all_reduce(t, op=dist.ReduceOp.SUM); out_real.copy_(t)
             else:
                 dist.all_reduce(out_real, op=dist.ReduceOp.SUM)
+            if ev:
+                ev[1].record(stream); comm_events.append(ev)
 
     def fence():
         if world > 1:
@@ -301,15 +377,39 @@ def worker_c3(args):
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     fence()
     dt = time.perf_counter() - t0
     prof = {k: eng.profile_read(k) for k in ("chain1d", "inverse", "assemble", "accumulate")}
+    inv_flops = eng.profile_read_flops("inverse")
     eng.profile(False)
+    comm_ms = sum(a.elapsed_time(b) for a, b in comm_events) / max(len(comm_events), 1) if comm_events else 0.0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    res_cold = out.cpu().numpy()
+    # warm steps: the same integral with the g(E) cache on -- one step fills it, the next ones only form
+    # Sigma = t g t^H; bit-identical result (asserted); NOT the headline
+    warm = None
+    if world == 1:
+        eng.set_chain_cache(8)
+        step(); fence()
+        eng.profile(True); eng.profile_reset()
+        t1 = time.perf_counter()
+        for _ in range(max(args.steps, 3)):
+            step()
+        fence()
+        warm_dt = (time.perf_counter() - t1) / max(args.steps, 3)
+        hit_ms, hit_n = eng.profile_read("chain1d_hit")
+        eng.profile(False)
+        assert np.array_equal(out.cpu().numpy(), res_cold), "a cached step must reproduce the cold step bit for bit"
+        st = eng.chain_cache_stats()
+        warm = {"warm_ms_per_step": warm_dt * 1e3, "warm_points_per_s": M / warm_dt,
+                "sigma_from_cached_g_ms": hit_ms / max(hit_n, 1), "cache_bytes": st["bytes"],
+                "note": "g(E) cache on (negf_set_chain_cache, default in the product): steps after the first reuse the "
+                        "surface Green's functions and only form Sigma = t g t^H; result bit-identical to the cold step"}
+        eng.set_chain_cache(0)
 
     info = eng.last_info_dev(M)
     assert not np.any(info), "singular pivot reported"
@@ -324,11 +424,16 @@ def worker_c3(args):
         ch_launches = max(ch_launches, 1); inv_launches = max(inv_launches, 1)
         sweeps_per_step = float(iters.sum())                           # this rank's shard, one pass
         flops_chain_step = float(np.sum(8.0 + 24.0 * iters + 16.0)) * NC ** 3
+        # issued to the matrix cores: per sweep the model of the instruction stream; the start inverse and the two
+        # products of Sigma = t g t^H are one inverse / two products of the same code
+        per_sweep = chain_mfma_flops_per_sweep(NC)
+        mfma_chain_step = float(np.sum(iters + 1.0)) * per_sweep
         launches_per_step = ch_launches / args.steps
         avg_chain_ms = ch_ms / ch_launches
-        achieved = flops_chain_step / launches_per_step / (avg_chain_ms * 1e-3) / 1e12 if ch_ms > 0 else 0.0
+        rl = roofline_pair(flops_chain_step / launches_per_step, mfma_chain_step / launches_per_step, avg_chain_ms * 1e-3)
         traffic, traffic_src = pmc_traffic_bytes("chain1d_rs_kernel")
-        inv_tf = 8.0 * N ** 3 * M * args.steps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
+        busy = pmc_counter("chain1d_rs_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
+        inv_rl = roofline_pair(inv_flops[0], inv_flops[1], inv_ms * 1e-3)
         line = {
             "metric": "energy-points/sec (complex128 G(E) solves)",
             "value": pts / dt,
@@ -349,13 +454,15 @@ def worker_c3(args):
                        "density_matrix_wall_ms": dt / args.steps * 1e3,
                        "sweeps_per_energy_and_contact_mean": float(iters.mean()),
                        "fixed_points_converged_frac": float(conv.mean())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", **rl, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac_means": "mfma_executed / peak (matrix-core flops issued, 3M form, tile padding); "
+                                       "frac_algorithmic = achieved / peak (8 flop per complex multiply-add, SURVEY 8d)",
+                         "mfma_busy_frac": (busy / (avg_chain_ms * 1e-3 * PEAK_CLOCK_HZ * N_SIMD)) if busy else None,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "chain1d_rs_kernel (1-D chain decimation fixed point, one workgroup per energy and contact)",
                          "avg_launch_ms": avg_chain_ms, "launches": ch_launches,
                          "sweeps_per_launch": sweeps_per_step / launches_per_step,
-                         "flops_per_sweep": 24.0 * NC ** 3,
+                         "flops_per_sweep": 24.0 * NC ** 3, "mfma_flops_per_sweep": per_sweep,
                          "algorithmic_flops_per_launch": flops_chain_step / launches_per_step,
                          # compulsory HBM bytes: the six lead matrices of both contacts once per launch (every
                          # workgroup re-reads them from L2) + one n_c x n_c Sigma block written per unit
@@ -363,8 +470,12 @@ def worker_c3(args):
                          "share_of_step": ch_ms / args.steps / (dt / args.steps * 1e3),
                          "other_ms_per_step": {"inverse": inv_ms / args.steps, "assemble": prof["assemble"][0] / args.steps,
                                                "accumulate": prof["accumulate"][0] / args.steps},
-                         "inverse_kernels_tflops": inv_tf},
+                         "inverse_kernels": inv_rl},
         }
+        if warm:
+            line["warm"] = warm
+        if world > 1:
+            line["comm_ms"] = comm_ms        # the sum all-reduce of the N_orb x N_orb result, per step (events on the stream)
         if not args.no_cpu and world == 1:           # the CPU leg is an N=1 figure (rank 0 only)
             import oracle
             ref = oracle.Chain1DSigma(F, S, inds, kw["taus"], kw["staus"], kw["alphas"], kw["aOverlaps"],
@@ -386,9 +497,17 @@ def worker_c3(args):
             line["cpu_baseline"]["one_process"] = {k: one[k] for k in ("value", "cores", "points_per_s_by_blas_threads", "sample")}
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / pool["value"]
             line["cpu_baseline"]["gpu_over_one_process"] = line["value"] / one["value"]
+            # the WHOLE host once: one single-thread oracle process per usable CPU (sched_getaffinity; the 16-process
+            # figure above is the CPU share a one-GPU box is meant to use) -- the reference's chunked Pool, density.py:121-210
+            ncpu = min(host_cpus(), int(os.environ.get("NEGF_BENCH_CPU_WORKERS_MAX", "256")))
+            if ncpu > pool["cores"] and not args.no_whole_host:
+                wh = cpu_baseline_pool("c3", (F, S, inds, kw, ETA), Er, wr, min(M, max(2 * ncpu, 128)), label, workers=ncpu)
+                wh.pop("_sum"); wh.pop("_idx")
+                wh["gpu_over_whole_host"] = line["value"] / wh["value"]
+                line["cpu_baseline"]["whole_host"] = wh
         if not args.no_extra and world == 1:
             line["extra"] = {"north_star_N500_x_1000": extra_const(eng, 500, 50, 1000, 3, reps=3, cpu_budget=6.0,
-                                                                   no_cpu=args.no_cpu),
+                                                                   no_cpu=args.no_cpu, whole_host=not args.no_whole_host),
                              "C2_N200_x_1000": extra_const(eng, 200, 20, 1000, 2, reps=10, cpu_budget=4.0,
                                                            no_cpu=args.no_cpu)}
         print(json.dumps(line), flush=True)
@@ -423,11 +542,11 @@ def worker_api(args):
         N = 800
         F, S = random_system(N, 4)
         coords, orbMap, orbTyp = _bethe_contacts(N)
-        lat = os.path.join(ROOT, "tests", "golden", "Au")
+        lat = os.path.join(ROOT, "gaunegf_amd", "data", "Au")
         g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
         Ec, wc = DN.contour_grid(-8.0, 0.0, 486, 0.0)
         Er, wr = DN.real_axis_grid(-1e6, -8.0, 256, 0.0)
-        pts_per_step, n_solve, solves_per_step, products_per_step = 742, N, 742, 0
+        pts_per_step = 742
         workload = ("C4: N_orb=800, Bethe-lattice Sigma (Au.bethe, 2 contacts x 3 atoms x 9 orbitals, eta=1e-6); one step = "
                     "GrInt over the 486-point ANT contour + GrInt over the 256-point real-axis grid, the grid sharded "
                     f"cyclically over {world} GPU(s), one sum all-reduce per integral")
@@ -450,14 +569,24 @@ def worker_api(args):
         M = 512
         Eg, wg = DN.bias_window_grid(-0.25, 0.25, M, 300.0)
         Et = np.real(np.asarray(Eg)).copy()
-        # two N = 1000 solves per energy and entry point (block-diagonal spin system), two dense products each
-        pts_per_step, n_solve, solves_per_step, products_per_step = 2 * M, N, 4 * M, 8 * M
+        # (two N = 1000 solves per energy and entry point: block-diagonal spin system)
+        pts_per_step = 2 * M
         workload = ("C5: 2 x 1000 spin-block F/S (scf.py:177-180 layout), qV=0.5 V window at 300 K, 512 Legendre points; one "
                     "step = GrLessInt(ind=-1) + calculate_transmission(spin='u') on that grid (each as two N=1000 solves per "
                     f"energy), the grid sharded cyclically over {world} GPU(s), one sum all-reduce / one all-gather each")
 
         def step():
             return GrLessInt(F, S, g, Eg, wg, -1), calculate_transmission(F, S, sc, Et, spin='u')
+
+    if args.emulate_share > 1:
+        assert world == 1, "--emulate-share is a one-GPU figure"
+        k = args.emulate_share
+        if args.config == "c4":
+            Ec, wc, Er, wr = Ec[0::k], wc[0::k], Er[0::k], wr[0::k]
+            pts_per_step = Ec.size + Er.size
+        else:
+            Eg, wg, Et = Eg[0::k], wg[0::k], Et[0::k]
+            pts_per_step = 2 * Eg.size
 
     def fence():
         if world > 1:
@@ -468,6 +597,7 @@ def worker_api(args):
         res = step()
     fence()
     eng.profile(True); eng.profile_reset()
+    D.comm_ms_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -476,6 +606,7 @@ def worker_api(args):
     dt = time.perf_counter() - t0
     fams = ("inverse", "zgemm", "bethe", "assemble", "accumulate", "gamma", "trace")
     prof = {k: eng.profile_read(k) for k in fams}
+    flops = {k: eng.profile_read_flops(k) for k in ("inverse", "zgemm")}
     eng.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else torch.device("cuda", local_rank))
@@ -483,12 +614,13 @@ def worker_api(args):
         dt = float(t.item())
     assert all(np.all(np.isfinite(np.asarray(r if not isinstance(r, tuple) else r[0]))) for r in res)
     if rank == 0:
-        share = 1.0 / world                               # this rank's part of the grid
         inv_ms = prof["inverse"][0]; gm_ms = prof["zgemm"][0]
-        inv_tf = 8.0 * n_solve ** 3 * solves_per_step * share * args.steps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
-        gm_tf = 8.0 * n_solve ** 3 * products_per_step * share * args.steps / (gm_ms * 1e-3) / 1e12 if gm_ms > 0 else 0.0
-        dom, dom_tf, dom_ms = ("zgemm_mfma_kernel (dense complex products G Gamma G^H, Gamma_L G Gamma_R G^H)", gm_tf, gm_ms) \
-            if gm_ms > inv_ms else ("windowed Gauss-Jordan inverse (gj_window* + gj_colupdate + gj_gather kernels)", inv_tf, inv_ms)
+        # flops as the library counted them for rank 0's launches (negf_profile_read_flops): algorithmic, and issued
+        # to the matrix cores (3M form, 16-granular tiles, upper block tiles of the Hermitian products)
+        inv_rl = roofline_pair(flops["inverse"][0], flops["inverse"][1], inv_ms * 1e-3)
+        gm_rl = roofline_pair(flops["zgemm"][0], flops["zgemm"][1], gm_ms * 1e-3)
+        dom, dom_rl, dom_ms = ("zgemm_mfma_kernel (dense complex products G Gamma G^H, Gamma_L G Gamma_R G^H)", gm_rl, gm_ms) \
+            if gm_ms > inv_ms else ("windowed Gauss-Jordan inverse (gj_window* + gj_colupdate + gj_gather kernels)", inv_rl, inv_ms)
         line = {
             "metric": "energy-points/sec (complex128 G(E) solves)",
             "value": args.steps * pts_per_step / dt, "unit": "energy-points/s", "n_gpus": world,
@@ -498,13 +630,22 @@ def worker_api(args):
             "config": {"workload": workload, "n_orb": N if args.config == "c4" else 2 * N,
                        "energy_points_per_step": pts_per_step, "sharding": f"energy-cyclic x{world}",
                        "density_matrix_wall_ms": dt / args.steps * 1e3},
-            "roofline": {"bound": "mfma", "achieved": dom_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": dom + " on rank 0's shard; 8 n^3 flop per solve / product",
+            "roofline": {"bound": "mfma", **dom_rl, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                         "frac_means": "mfma_executed / peak (matrix-core flops issued: 3M form, 16-granular tiles, upper "
+                                       "block tiles of Hermitian products); frac_algorithmic = achieved / peak (8 n^3 per "
+                                       "solve, 8 M N K per product)",
+                         "kernel": dom + " on rank 0's shard",
                          "family_ms_per_step": {k: prof[k][0] / args.steps for k in fams},
-                         "inverse_tflops": inv_tf, "zgemm_tflops": gm_tf,
+                         "inverse": inv_rl, "zgemm": gm_rl,
                          "share_of_step": dom_ms / args.steps / (dt / args.steps * 1e3)},
         }
+        if args.emulate_share > 1:
+            line["config"]["emulated_share"] = (f"rank 0's share of an {args.emulate_share}-way energy-cyclic sharding run on "
+                                                "one GPU (no collective): the per-GPU batch sizes of the multi-GPU configuration")
+        if world > 1:
+            cm, calls = D.comm_ms_total()
+            line["comm_ms"] = cm / args.steps          # the all-reduces / all-gathers of one step (events around the collectives)
+            line["collectives_per_step"] = calls / args.steps
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -512,7 +653,132 @@ def worker_api(args):
         dist.destroy_process_group()
 
 
-def extra_const(eng, N, nc, M, seed, reps, cpu_budget, no_cpu):
+# ------------------------------------------------------------------------- the SCF call pattern
+SCF_FAMILIES = ("inverse", "assemble", "accumulate", "zgemm", "gamma", "trace", "chain1d", "chain1d_hit", "bethe", "small")
+
+
+def _scf_system(name):
+    """(label, F, S, g_dev, make_ref, ne, Eminf): the systems of --config scf.  make_ref() -> the oracle's provider of
+    the same contacts (None where a CPU replay of the step would take minutes)."""
+    import oracle  # noqa: F401  (only used by make_ref, after the timed region)
+    if name in ("n60", "n200"):
+        from gaunegf_amd.surfGTester import surfGTest
+        N, nc = (60, 6) if name == "n60" else (200, 20)
+        F, S = random_system(N, 60 if name == "n60" else 2)
+        inds = [list(range(nc)), list(range(N - nc, N))]
+        g = surfGTest(F, S, inds, -0.1j)
+        label = (f"N_orb={N}, energy-independent Gamma=0.2 eV contacts on {nc} orbitals each "
+                 f"({'C1-sized: the ethane demo has 60 basis functions' if N == 60 else 'C2-sized'})")
+        return label, F, S, g, (lambda: __import__("oracle").ConstSigma(F, S, inds, -0.1j)), N, -60.0
+    if name == "n800":
+        from gaunegf_amd.surfGBethe import surfGB
+        N = 800
+        F, S = random_system(N, 4)
+        coords, orbMap, orbTyp = _bethe_contacts(N)
+        lat = os.path.join(ROOT, "gaunegf_amd", "data", "Au")
+        g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
+        return "N_orb=800 + Bethe-lattice Sigma (Au.bethe, 2 contacts x 3 atoms x 9 orbitals): C4-sized", F, S, g, None, N, -60.0
+    if name == "chain":
+        from gaunegf_amd.surfG1D import surfG
+        N, nc = 120, 20
+        F, S = random_system(N, 7)
+        aL = chain_lead(nc, 71); aR = chain_lead(nc, 72)
+        inds = [list(range(nc)), list(range(N - nc, N))]
+        kw = dict(taus=[aL[2].copy(), aR[2].copy()], staus=[aL[3].copy(), aR[3].copy()], alphas=[aL[0], aR[0]],
+                  aOverlaps=[aL[1], aR[1]], betas=[aL[2], aR[2]], bOverlaps=[aL[3], aR[3]], eta=1e-3)
+        g = surfG(F, S, inds, **kw)
+        return ("N_orb=120 + two 1-D chain leads (n_c=20, eta=1e-3, reference stopping rule): the g(E) cache's case", F, S, g,
+                None, N, -60.0)
+    raise SystemExit(f"unknown scf system {name}")
+
+
+def worker_scf(args):
+    """One NEGFE.FockToP step (scfE.py:301-462) per system: adaptive real-axis integral below Emin, a Muller Fermi search
+    whose every probe is an adaptive ANT contour integral (levels 2 ... 486 points, density.py:211-273, 750-816), and the
+    adaptive bias-window integral -- the call pattern the hot path is used in: ~10^2 integrals of 2 ... 324 points.
+    Reports wall time per step, integrals and energy points per step, and the split kernel time (the library's
+    hipEvents around its kernel families) / everything else (host code, launch gaps, transfers)."""
+    import contextlib
+    import io
+    import torch
+    from gaunegf_amd import density as DN
+    from gaunegf_amd.engine import get_engine
+    from gaunegf_amd.scfE import NEGFE
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    eng = get_engine()
+    names = [x for x in args.scf_systems.split(",") if x]
+    out_sys = []
+    for name in names:
+        label, F, S, g, make_ref, ne, Eminf = _scf_system(name)
+        qV, T, tol = 0.1, 300.0, 1e-4
+
+        def new_step(gobj):
+            n = NEGFE(F, S, gobj, ne=ne, spin='r', T=T, Eminf=Eminf)
+            n.setIntegralLimits(tol=tol, Emin=None)            # adaptive integrals everywhere; Emin from the DOS
+            n.setVoltage(qV, fermiMethod='muller')             # Fermi level searched (updFermi), bias window open
+            return n
+        sink = io.StringIO()
+        variants = [("", {})]
+        if name == "chain":
+            variants = [("cache_off", {"cache": 0}), ("cache_on", {"cache": 8})]
+        for vname, opt in variants:
+            if "cache" in opt:
+                eng.set_chain_cache(0); eng.set_chain_cache(opt["cache"])
+            with contextlib.redirect_stdout(sink):
+                for _ in range(max(args.warmup, 1)):
+                    new_step(g).FockToP()
+                steps = [new_step(g) for _ in range(args.steps)]
+                torch.cuda.synchronize()
+                c0 = dict(eng.counters)
+                eng.profile(True); eng.profile_reset()
+                t0 = time.perf_counter()
+                for n in steps:
+                    n.FockToP()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / args.steps
+                fam = {k: eng.profile_read(k) for k in SCF_FAMILIES}
+                eng.profile(False)
+            calls = (eng.counters["calls"] - c0["calls"]) / args.steps
+            pts = (eng.counters["points"] - c0["points"]) / args.steps
+            kern_ms = sum(v[0] for v in fam.values()) / args.steps
+            rec = {"system": name + ("/" + vname if vname else ""), "workload": label, "n_orb": len(F),
+                   "wall_ms_per_step": dt * 1e3, "integrals_per_step": calls, "energy_points_per_step": pts,
+                   "points_per_s": pts / dt, "kernel_ms_per_step": kern_ms,
+                   "host_launch_gap_transfer_ms_per_step": dt * 1e3 - kern_ms,
+                   "kernel_share": kern_ms / (dt * 1e3),
+                   "profiled_kernel_groups_per_step": sum(v[1] for v in fam.values()) / args.steps,
+                   "family_ms_per_step": {k: v[0] / args.steps for k, v in fam.items() if v[1]},
+                   "fermi": float(steps[-1].fermi), "electrons": float(np.real(np.trace(steps[-1].P @ S)))}
+            if "cache" in opt:
+                rec["chain_cache"] = eng.chain_cache_stats()
+            # parity: the same step replayed with the numpy oracle serving every integral (bounded: small systems)
+            if make_ref is not None and not args.no_cpu:
+                import oracle
+                saved = (DN.GrInt, DN.GrLessInt, DN._compute_dos_at_energy)
+                DN.GrInt, DN.GrLessInt, DN._compute_dos_at_energy = oracle.GrInt, oracle.GrLessInt, oracle.dos_at_energy
+                try:
+                    with contextlib.redirect_stdout(sink):
+                        t1 = time.perf_counter(); ref = new_step(make_ref()); ref.FockToP(); cpu_dt = time.perf_counter() - t1
+                finally:
+                    DN.GrInt, DN.GrLessInt, DN._compute_dos_at_energy = saved
+                rec["parity_rel_fro_P_vs_oracle_replay"] = float(np.linalg.norm(steps[-1].P - ref.P) / np.linalg.norm(ref.P))
+                rec["parity_fermi_abs_diff"] = float(abs(steps[-1].fermi - ref.fermi))
+                rec["cpu_oracle_replay_ms"] = cpu_dt * 1e3
+                assert rec["parity_rel_fro_P_vs_oracle_replay"] < 1e-8, rec
+            out_sys.append(rec)
+    eng.set_chain_cache(0); eng.set_chain_cache(8)
+    head = out_sys[0]
+    line = {"metric": "density-matrix wall time, one NEGFE.FockToP step (adaptive contour + real axis + Muller Fermi search + bias window)",
+            "value": head["wall_ms_per_step"], "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": head["wall_ms_per_step"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 (complex128)", "data": "synthetic",
+            "config": {"workload": "SCF call pattern (SURVEY 3.5(4), scfE.py:301-462): " + head["workload"], "systems": out_sys}}
+    print(json.dumps(line), flush=True)
+
+
+
+def extra_const(eng, N, nc, M, seed, reps, cpu_budget, no_cpu, whole_host=False):
     """Constant-Sigma GrInt (BASELINE C2 / the north-star sentence's N_orb=500 x 1000 case): device-resident
     timing like the headline, roofline of the dense inverse kernels, CPU sample."""
     import torch
@@ -539,10 +805,10 @@ def extra_const(eng, N, nc, M, seed, reps, cpu_budget, no_cpu):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     inv_ms, inv_l = eng.profile_read("inverse")
+    fl = eng.profile_read_flops("inverse")
     eng.profile(False)
-    tf = 8.0 * N ** 3 * M * reps / (inv_ms * 1e-3) / 1e12 if inv_ms > 0 else 0.0
     res = {"n_orb": N, "energies": M, "gpu_ms_per_density_matrix": dt * 1e3, "gpu_points_per_s": M / dt,
-           "inverse_ms_per_pass": inv_ms / reps, "inverse_tflops": tf, "inverse_frac_of_fp64_peak": tf / FP64_MFMA_PEAK_TFLOPS}
+           "inverse_ms_per_pass": inv_ms / reps, "inverse_roofline": roofline_pair(fl[0], fl[1], inv_ms * 1e-3)}
     if not no_cpu:
         import oracle
         g = oracle.ConstSigma(F, S, inds, -0.1j)
@@ -550,6 +816,14 @@ def extra_const(eng, N, nc, M, seed, reps, cpu_budget, no_cpu):
                            f"the same N_orb={N} constant-Sigma workload", budget_s=cpu_budget, probe_pts=4)
         res.update({"cpu_points_per_s": cpu["value"], "cpu_cores": cpu["cores"], "cpu_sample": cpu["sample"],
                     "speedup": (M / dt) / cpu["value"]})
+        ncpu = min(host_cpus(), int(os.environ.get("NEGF_BENCH_CPU_WORKERS_MAX", "256")))
+        if whole_host and ncpu > 1:
+            # north_star's target sentence (">= 10x the reference CPU density-matrix build"), against the whole host:
+            # one single-thread oracle process per usable CPU over a sample of the grid
+            wh = cpu_baseline_pool("const", (F, S, inds, -0.1j), E, w, min(M, max(2 * ncpu, 128)),
+                                   f"the same N_orb={N} constant-Sigma workload", workers=ncpu)
+            wh.pop("_sum"); wh.pop("_idx")
+            res["cpu_whole_host"] = {**wh, "gpu_over_whole_host": (M / dt) / wh["value"]}
     eng.sigma_free(h)
     return res
 
@@ -564,11 +838,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("c3", "c4", "c5"), default="c3",
-                    help="BASELINE configuration: c3 = the headline (weak scaling); c4, c5 = the multi-GPU configurations (strong scaling)")
+    ap.add_argument("--config", choices=("c3", "c4", "c5", "scf"), default="c3",
+                    help="BASELINE configuration: c3 = the headline (weak scaling); c4, c5 = the multi-GPU configurations "
+                         "(strong scaling); scf = one NEGFE.FockToP step (the call pattern of an SCF run), one GPU")
+    ap.add_argument("--scf-systems", default="n60,n200,n800,chain", help="systems of --config scf (comma separated)")
     ap.add_argument("--energies", type=int, default=2000, help="energy points per GPU (c3)")
+    ap.add_argument("--emulate-share", type=int, default=1,
+                    help="c4 / c5 on one GPU: run only rank 0's share of a K-way energy-cyclic sharding (the small per-GPU batches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the N_orb=500 x 1000 and C2 secondary lines")
+    ap.add_argument("--no-whole-host", action="store_true", help="skip the CPU pools over ALL usable CPUs (keep the 16-process ones)")
     ap.add_argument("--cpu-budget", type=float, default=18.0, help="seconds of CPU work for the headline baseline")
     args = ap.parse_args()
 
@@ -582,6 +861,10 @@ def main():
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.config == "scf":
+        if args.gpus != 1:
+            raise SystemExit("--config scf is a one-GPU figure")
+        return worker_scf(args)
     (worker_c3 if args.config == "c3" else worker_api)(args)
 
 

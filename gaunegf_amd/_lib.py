@@ -57,9 +57,14 @@ SIGNATURES = {
     "negf_sync": (C.c_int, [_vp]),
     "negf_last_info": (C.c_int, [_vp, C.c_int, _vp]),
     "negf_last_iters": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "negf_set_chain_cache": (C.c_int, [_vp, C.c_int]),
+    "negf_chain_cache_clear": (C.c_int, [_vp]),
+    "negf_chain_cache_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                         C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "negf_profile_enable": (C.c_int, [_vp, C.c_int]),
     "negf_profile_reset": (C.c_int, [_vp]),
     "negf_profile_read": (C.c_int, [_vp, C.c_char_p, _dp, _ip]),
+    "negf_profile_read_flops": (C.c_int, [_vp, C.c_char_p, _dp, _dp]),
     "negf_set_inverse_algo": (C.c_int, [_vp, C.c_int]),
     "negf_set_gamma_algo": (C.c_int, [_vp, C.c_int]),
     "negf_selftest_mfma": (C.c_int, [_vp, _dp]),

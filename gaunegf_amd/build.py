@@ -37,7 +37,10 @@ def _hipcc():
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    """Compile every .hip translation unit for gfx950 and link the shared library."""
+    """Compile every .hip translation unit for gfx950 and link the shared library.
+    NEGF_EXTRA_HIPCC_FLAGS adds flags for diagnostic builds (e.g. -DRS_STAMPS=1: the chain kernel's phase stamps);
+    use it with force=True / --force."""
+    extra_flags = tuple(extra_flags) + tuple(os.environ.get("NEGF_EXTRA_HIPCC_FLAGS", "").split())
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()

@@ -51,6 +51,10 @@ constexpr int RS_NB = RS_PANEL;           // panel width of the small inverse: h
 #ifndef RS_ROW_MODE
 #define RS_ROW_MODE 0                 // pivot row of the factoring wave: 0 LDS line (round 2), 1 v_readlane, 2 ds_bpermute
 #endif
+#ifndef RS_STAMPS
+#define RS_STAMPS 0                   // 1: diagnostic build -- the phase / cycle stamps of NEGF_CHAIN_STAMPS=1 are compiled in
+#endif                                //    (NEGF_EXTRA_HIPCC_FLAGS=-DRS_STAMPS=1 python -m gaunegf_amd.build --force); the production
+                                      //    kernel carries none of their branches
 
 struct ChainRsArgs {
     const cplx *alpha, *Salpha, *beta, *Sbeta, *tau, *Stau;   // concatenated per contact
@@ -62,7 +66,12 @@ struct ChainRsArgs {
     cplx* gold;                      // [workgroups][KS][256] lane-private copies of the iterate (GOLD_GLOBAL kernels)
     int gold_lds_off, gold_lds_slots; // the first slots of a lane's copy live in LDS at this element offset
     const int* order;                // launch slot -> job (energy * n_contacts + contact), longest jobs first; or null
-    unsigned long long* stamps;      // diagnostic (NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
+    // surface Green's function cache (negf_set_chain_cache): gc_mode 1 = this launch is a miss, every job stores its
+    // final iterate g into gcache [energy][blk_stride] (the layout of blk); 2 = a hit, every job loads g from there and
+    // only runs Sigma = t g t^H -- the same instructions on the same operands as the last pass of a miss
+    cplx* gcache;
+    int gc_mode;
+    unsigned long long* stamps;      // diagnostic (RS_STAMPS build + NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
     int stamp_sweep;                 // diagnostic: the sweep of job 0 whose phases are stamped (NEGF_CHAIN_STAMP_SWEEP, default 10)
     int simd_roles;                  // 1: wave roles follow the SIMD a wave runs on (see rs_wave_role), 0: the wave number
 };
@@ -776,9 +785,19 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     };
 
     // ---- g0 = inv(A); the padding of the work matrix is zeroed once and never written again
-    for (int t = tid; t < WELEMS; t += RS_THREADS) {
-        const int i = t / P, j = t - i * P;
-        Ws[t] = sel(i < n && j < n, Aat(i, j));
+    // (a cache hit starts from the stored iterate instead and goes straight to Sigma = t g t^H)
+    const bool gc_hit = a.gc_mode == 2;
+    if (gc_hit) {
+        const cplx* gcj = a.gcache + (size_t)b * a.blk_stride + off;
+        for (int t = tid; t < WELEMS; t += RS_THREADS) {
+            const int i = t / P, j = t - i * P;
+            Ws[t] = sel(i < n && j < n, gcj[min(i, n - 1) * n + min(j, n - 1)]);
+        }
+    } else {
+        for (int t = tid; t < WELEMS; t += RS_THREADS) {
+            const int i = t / P, j = t - i * P;
+            Ws[t] = sel(i < n && j < n, Aat(i, j));
+        }
     }
     if (tid < 64) { colof[tid] = -1; pivrow[tid] = 0; }
     __syncthreads();
@@ -790,17 +809,23 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     int count = 0;
     bool first = true, final_pass = false;
     while (true) {
-        unsigned long long* st = (a.stamps && job == 0 && count == a.stamp_sweep) ? a.stamps : nullptr;
+        unsigned long long* st = (RS_STAMPS && a.stamps && job == 0 && count == a.stamp_sweep) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-        rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
-        if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
-        gather_mix(first, st);
-        if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
-        if (!first) ++count;
-        first = false;
-        if (a.force_iters >= 0 ? count >= a.force_iters : !(over && count < a.max_iter)) {
+        if (!gc_hit) {
+            rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
+            if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+            gather_mix(first, st);
+            if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
+            if (!first) ++count;
+            first = false;
+        }
+        if (gc_hit || (a.force_iters >= 0 ? count >= a.force_iters : !(over && count < a.max_iter))) {
             final_pass = true;
             opS = Stau; opM = tau; opz = e;
+            if (a.gc_mode == 1) {                       // a miss leaves its final iterate in the cache (g sits in Ws, complete
+                cplx* gcj = a.gcache + (size_t)b * a.blk_stride + off;                              //  since the barrier that ends gather_mix)
+                for (int t = tid; t < n * n; t += RS_THREADS) { const int i = t / n; gcj[t] = Ws[i * P + (t - i * n)]; }
+            }
         }
         d4 mr[T16], mi[T16], mc[T16];
         // T = B g : row tile `wave`; g is read from Ws by every wave, so T waits in registers
@@ -833,7 +858,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         __syncthreads();
         if (st && tid == 0) st[4] = __builtin_amdgcn_s_memrealtime();
     }
-    if (tid == 0) {
+    if (tid == 0 && !gc_hit) {                           // (a hit's counts and flags are copied from the cache by the launcher's caller)
         if (iters) iters[(size_t)b * a.n_contacts + c] = count;
         if (converged) converged[(size_t)b * a.n_contacts + c] = (count > 0 && allok) ? 1 : 0;
     }
@@ -972,10 +997,12 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
 }  // namespace
 
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
-                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order)
+                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
+                        cplx* gcache, int gc_mode)
 {
     ChainRsArgs a;
     a.order = order;
+    a.gcache = gcache; a.gc_mode = gcache ? gc_mode : 0;
     a.alpha = p.d_alpha; a.Salpha = p.d_Salpha; a.beta = p.d_beta; a.Sbeta = p.d_Sbeta;
     a.tau = p.d_tau; a.Stau = p.d_Stau;
     a.nc = d_nc; a.blk_off = d_blk_off;
@@ -997,9 +1024,21 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     if (roles_env < 0) { const char* e = getenv("NEGF_CHAIN1D_ROLES"); roles_env = e ? atoi(e) : 1; }
     a.simd_roles = roles_env;
     // one instantiation per pitch class of the largest contact (smaller contacts of the same launch run
-    // in the same padded matrix): the smallest odd pitch of the list that holds n_max columns
-    const int n = p.nc_max;
-#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env)
+    // in the same padded matrix): the smallest odd pitch of the list that holds n_max columns.  The remainder-strip
+    // classes (19, 35, 51: the last tile holds <= 4 rows / columns and runs on the 4x4x4 instruction) store their
+    // full tiles unguarded and count every k-step below the strip as inside the matrix, i.e. they assume that EVERY
+    // contact of the launch reaches into the strip, n > 16 TR.  A launch whose smallest contact does not (contacts of
+    // unequal size, e.g. n_c = (50, 40)) takes the next class without strips, whose stores and k-steps are guarded
+    // by the contact's own n.
+    const int n_max = p.nc_max;
+    int n = n_max;                                  // selects the class
+    {
+        int n_min = n;
+        for (int k : p.nc) n_min = std::min(n_min, k);
+        const int strip_base = n <= 16 ? -1 : n <= 19 ? 16 : (n > 32 && n <= 35) ? 32 : (n > 48 && n <= 51) ? 48 : -1;
+        if (strip_base > 0 && n_min <= strip_base) n = strip_base == 16 ? 25 : strip_base == 32 ? 41 : 57;
+    }
+#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n_max, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env)
 #ifdef RS_FAST_BUILD
     if (n <= 16) RS_CASE(17); else RS_CASE(51);
 #else

@@ -23,6 +23,7 @@
 // Workgroup = 256 threads = 4 waves; block tile 64 x 64, wave tile 32 x 32
 // (2 x 2 MFMA tiles, 64 accumulator VGPRs), K tile 16 staged through LDS.
 #include "negf_common.h"
+#include <algorithm>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -424,6 +425,18 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
     static int herm_env = -1;                    // NEGF_ZGEMM_HERM=0: compute Hermitian products in full (A/B, tests)
     if (herm_env < 0) { const char* e = getenv("NEGF_ZGEMM_HERM"); herm_env = e ? atoi(e) : 1; }
     if (!herm_env) opB &= 1;
+    {   // flop accounting (negf_common.h, FlopCount): 16 x 16 sub-tiles that hold part of the result, K padded to the
+        // staged K-tile, three real products per sub-tile and k-step; a Hermitian product runs the sub-tiles of the
+        // block tiles on and above the diagonal only
+        const double tm = (M + 15) >> 4, tn = (N + 15) >> 4, kp = (double)((K + ZG_BK - 1) / ZG_BK * ZG_BK);
+        double tiles = tm * tn;
+        if (opB & 2) {
+            const int bt = 4;                               // sub-tiles per block-tile edge (64 x 64 blocks; the flexible
+            tiles = 0;                                      //  blocks are of similar size)
+            for (int tj = 0; tj < (int)tn; ++tj) tiles += std::min<double>(tm, bt * (tj / bt + 1));
+        }
+        negf_count_flops(8.0 * M * (double)N * K * nb, zgemm_algo() == 1 ? 0.0 : 3.0 * 2.0 * 256.0 * kp * tiles * nb);
+    }
     if (zgemm_algo() == 1) {
         dim3 grid((N + 31) / 32, (M + 31) / 32, nb);
         hipLaunchKernelGGL(zgemm_valu_kernel, grid, dim3(256), 0, st, M, N, K, A, lda, strideA, B, ldb,

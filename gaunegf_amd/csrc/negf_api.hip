@@ -14,16 +14,21 @@ static hipEvent_t prof_get_event(negf_ctx* c)
     return e;
 }
 
+FlopCount g_negf_flops;
+
 ProfScope::ProfScope(negf_ctx* ctx, const char* nm) : c(ctx), name(nm)
 {
     if (!c->profiling) return;
+    f0 = g_negf_flops;
     e0 = prof_get_event(c); e1 = prof_get_event(c);
     if (e0) (void)hipEventRecord(e0, c->stream);
 }
 
 ProfScope::~ProfScope()
 {
-    if (!c->profiling || !e0 || !e1) return;
+    if (!c->profiling) return;
+    { auto& e = c->prof[name]; e.flops_alg += g_negf_flops.alg - f0.alg; e.flops_mfma += g_negf_flops.mfma - f0.mfma; }
+    if (!e0 || !e1) return;
     (void)hipEventRecord(e1, c->stream);
     c->prof_pending.push_back({name, e0, e1});
 }
@@ -79,7 +84,7 @@ void free_provider(SigmaProvider* p)
     dev_free(p->d_inds); dev_free(p->d_nc); dev_free(p->d_blk_off); dev_free(p->d_inds_off);
     dev_free(p->d_n_atoms); dev_free(p->d_atom_off);
     dev_free(p->d_alpha); dev_free(p->d_Salpha); dev_free(p->d_beta); dev_free(p->d_Sbeta);
-    dev_free(p->d_tau); dev_free(p->d_Stau); dev_free(p->d_lead_pad);
+    dev_free(p->d_tau); dev_free(p->d_Stau);
     dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
     dev_free(p->d_H); dev_free(p->d_Slist); dev_free(p->d_Vlist); dev_free(p->d_xi);
     dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order); dev_free(p->d_prevE); dev_free(p->d_prev_iters);
@@ -97,7 +102,77 @@ void free_mbuffers(negf_ctx* c)
 {
     dev_free(c->d_info); dev_free(c->d_iters); dev_free(c->d_conv);
     dev_free(c->d_E); dev_free(c->d_w); dev_free(c->d_scal);
-    c->m_cap = 0; c->contacts_cap = 0;
+    c->m_cap = 0; c->contacts_cap = 0; c->h_E_valid = false;
+}
+
+void free_gentry(ChainGEntry& e)
+{
+    dev_free(e.d_g); dev_free(e.d_it); dev_free(e.d_cv);
+    e.g_cap = 0; e.it_cap = 0; e.valid = false;
+}
+
+void free_gcache(negf_ctx* c)
+{
+    for (auto& e : c->gcache) free_gentry(e);
+    c->gcache.clear();
+}
+
+// 64-bit mixing hash over the 8-byte words of a buffer (a filter in front of the bitwise comparisons of the g(E) cache)
+unsigned long long hash_words(const void* data, size_t bytes, unsigned long long h = 0x9E3779B97F4A7C15ull)
+{
+    const unsigned long long* w = static_cast<const unsigned long long*>(data);
+    for (size_t i = 0; i < bytes / 8; ++i) { h = (h ^ w[i]) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    return h;
+}
+
+// the energies E_dev[0..nb) on the host: the copy stage_grid kept when they are the staged grid, a download otherwise
+const cplx* host_energies(negf_ctx* c, const cplx* E_dev, int nb, std::vector<cplx>& tmp)
+{
+    if (c->h_E_valid && c->d_E && E_dev >= c->d_E && E_dev + nb <= c->d_E + c->h_E.size())
+        return c->h_E.data() + (E_dev - c->d_E);
+    tmp.resize((size_t)nb);
+    if (hipMemcpyAsync(tmp.data(), E_dev, (size_t)nb * sizeof(cplx), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return tmp.data();
+}
+
+// Look the launch (provider p, energies Eh[0..nb)) up in the context's g(E) cache.  *hit: the entry holds it.  Otherwise
+// the returned entry (least recently used, or a new one) has room for it and is to be filled by the launch; nullptr:
+// not cached (cache off, entry too large, out of memory).
+ChainGEntry* gcache_lookup(negf_ctx* c, const SigmaProvider* p, const cplx* Eh, int nb, bool* hit)
+{
+    *hit = false;
+    if (c->gcache_max <= 0 || !Eh || nb <= 0 || p->h_lead.empty()) return nullptr;
+    const size_t g_elems = (size_t)nb * p->blk_stride, it_elems = (size_t)nb * p->n_contacts;
+    if (g_elems * sizeof(cplx) > c->gcache_entry_bytes_max) return nullptr;
+    const unsigned long long eh = hash_words(Eh, (size_t)nb * sizeof(cplx));
+    for (auto& e : c->gcache) {
+        if (!e.valid || e.E_hash != eh || e.lead_hash != p->lead_hash || (int)e.E.size() != nb) continue;
+        if (e.eta != p->eta || e.conv != p->conv || e.relFactor != p->relFactor || e.max_iter != p->max_iter ||
+            e.force_iters != p->force_iters || e.nc != p->nc) continue;
+        if (std::memcmp(e.E.data(), Eh, (size_t)nb * sizeof(cplx)) != 0) continue;
+        if (e.lead.size() != p->h_lead.size() || std::memcmp(e.lead.data(), p->h_lead.data(), e.lead.size() * sizeof(cplx)) != 0) continue;
+        e.used = ++c->gcache_clock;
+        ++c->gcache_hits;
+        *hit = true;
+        return &e;
+    }
+    ++c->gcache_misses;
+    ChainGEntry* v = nullptr;
+    if ((int)c->gcache.size() < c->gcache_max) { c->gcache.emplace_back(); v = &c->gcache.back(); }
+    else for (auto& e : c->gcache) if (!v || !e.valid || (v->valid && e.used < v->used)) v = &e;
+    v->valid = false;
+    if (g_elems > v->g_cap || it_elems > v->it_cap) {
+        (void)hipStreamSynchronize(c->stream);              // kernels of earlier calls may still read the old buffers
+        free_gentry(*v);
+        if (dev_alloc(&v->d_g, g_elems) || dev_alloc(&v->d_it, it_elems) || dev_alloc(&v->d_cv, it_elems)) { free_gentry(*v); return nullptr; }
+        v->g_cap = g_elems; v->it_cap = it_elems;
+    }
+    v->nc = p->nc; v->lead = p->h_lead; v->lead_hash = p->lead_hash; v->E_hash = eh;
+    v->eta = p->eta; v->conv = p->conv; v->relFactor = p->relFactor; v->max_iter = p->max_iter; v->force_iters = p->force_iters;
+    v->E.assign(Eh, Eh + nb);
+    v->used = ++c->gcache_clock;
+    return v;
 }
 
 // Energies in flight for a grid of m points.  Once the transmission entry point has been used on this context
@@ -205,6 +280,11 @@ int run_inverse(negf_ctx* c, int nb, int* info)
     }
     if (algo == 1 && !launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info)) return NEGF_EINVAL;
     NEGF_HIP_CHECK(hipGetLastError());
+    {   // 8 n^3 algorithmic; the blocked kernels run every rank-NB update on the matrix cores in 3M form over
+        // 16-granular tiles (the pivot steps themselves are vector work), the unblocked kernel none of it
+        const double n = c->n, np = (double)((c->n + 15) & ~15);
+        negf_count_flops(8.0 * n * n * n * nb, algo == 2 ? 6.0 * n * np * np * nb : 0.0);
+    }
     c->G = in_b ? c->d_T1 : c->d_A;
     c->W1 = in_b ? c->d_A : c->d_T1;
     c->W2 = c->d_T2;
@@ -215,10 +295,18 @@ int run_inverse(negf_ctx* c, int nb, int* info)
 int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* iters, int* conv)
 {
     if (p->kind == SK_CHAIN1D) {
-        ProfScope ps(c, "chain1d");
         static int force_v1 = -1;
         if (force_v1 < 0) { const char* e = getenv("NEGF_CHAIN1D_ALGO"); force_v1 = (e && strcmp(e, "global") == 0) ? 1 : 0; }
-        if (chain1d_lds_supported(p->nc_max) && !force_v1) {
+        const bool lds_path = chain1d_lds_supported(p->nc_max) && !force_v1;
+        // the g(E) cache (ChainGEntry): a launch whose lead and energies were evaluated before only forms Sigma = t g t^H
+        ChainGEntry* ent = nullptr;
+        bool hit = false;
+        if (lds_path && c->gcache_max > 0) {
+            std::vector<cplx> tmp;
+            ent = gcache_lookup(c, p, host_energies(c, E, nb, tmp), nb, &hit);
+        }
+        ProfScope ps(c, hit ? "chain1d_hit" : "chain1d");
+        if (lds_path) {
             const size_t need = chain1d_lds_scratch_elems(p->nc_max, p->n_contacts, nb);
             if (need > c->scratch_cap) {
                 NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -227,11 +315,18 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                 if (rc) return rc;
                 c->scratch_cap = need;
             }
+            const int jobs = nb * p->n_contacts;
+            if (hit) {
+                launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, nullptr, ent->d_g, 2);
+                if (iters) NEGF_HIP_CHECK(hipMemcpyAsync(iters, ent->d_it, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                if (conv) NEGF_HIP_CHECK(hipMemcpyAsync(conv, ent->d_cv, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                return NEGF_OK;
+            }
+            if (ent && (!iters || !conv)) ent = nullptr;    // (an entry carries the counts and flags of its launch)
             // jobs in the order of decreasing sweep counts: the counts are predicted from the previous evaluation of
             // this provider -- for each energy the count of the nearest energy evaluated then (Fermi searches and SCF
             // cycles evaluate the same or slightly moved grids over and over; the same grid gets exactly its learned
             // order) -- and sorted on the device, no host sync; the first evaluation runs in launch order
-            const int jobs = nb * p->n_contacts;
             const bool can_order = p->force_iters < 0 && iters && chain1d_order_supported(jobs);
             const int* order = nullptr;
             if (can_order) {
@@ -247,7 +342,13 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                     order = p->d_order;
                 }
             }
-            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, order);
+            launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, order,
+                               ent ? ent->d_g : nullptr, 1);
+            if (ent) {
+                NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_it, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_cv, conv, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                ent->valid = true;
+            }
             if (can_order) {
                 // keep this evaluation's energies and counts for the next prediction
                 if (nb > p->prev_cap) {
@@ -481,6 +582,8 @@ int negf_create(negf_ctx** out, int device)
     negf_ctx* c = new (std::nothrow) negf_ctx();
     if (!c) return NEGF_ENOMEM;
     c->device = device;
+    if (const char* e = getenv("NEGF_CHAIN_CACHE")) c->gcache_max = std::min(std::max(atoi(e), 0), 4096);   // default of negf_set_chain_cache
+    c->gcache.reserve((size_t)c->gcache_max);
     *out = c;
     return NEGF_OK;
 }
@@ -491,7 +594,7 @@ void negf_destroy(negf_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto* p : c->providers) free_provider(p);
-    free_workspace(c); free_mbuffers(c);
+    free_workspace(c); free_mbuffers(c); free_gcache(c);
     for (auto& sl : c->sys) { dev_free(sl.dF); dev_free(sl.dS); }
     c->d_F = c->d_S = nullptr;
     dev_free(c->d_acc);
@@ -696,20 +799,13 @@ int negf_sigma_chain1d(negf_ctx* c, int n_contacts, const int* nc, const int* in
         if ((rc = dev_alloc(dsts[k], tot)) ||
             (rc = upload(c, *dsts[k], reinterpret_cast<const cplx*>(srcs[k]), tot))) { free_provider(p); return rc; }
     }
-    if (chain1d_lds_supported(p->nc_max)) {
-        constexpr int LP = 64;
-        std::vector<cplx> pad((size_t)n_contacts * 6 * LP * LP, cmake(0.0, 0.0));
-        for (int k = 0; k < n_contacts; ++k)
-            for (int m = 0; m < 6; ++m) {
-                const cplx* src = reinterpret_cast<const cplx*>(srcs[m]) + p->blk_off[k];
-                cplx* dst = pad.data() + ((size_t)k * 6 + m) * LP * LP;
-                for (int i = 0; i < nc[k]; ++i)
-                    for (int j = 0; j < nc[k]; ++j) dst[i * LP + j] = src[i * nc[k] + j];
-            }
-        if ((rc = dev_alloc(&p->d_lead_pad, pad.size())) || (rc = upload(c, p->d_lead_pad, pad.data(), pad.size()))) {
-            free_provider(p); return rc;
-        }
+    // what g(E) depends on, for the context's g(E) cache
+    p->h_lead.reserve(4 * tot);
+    for (int k = 0; k < 4; ++k) {
+        const cplx* src = reinterpret_cast<const cplx*>(srcs[k]);
+        p->h_lead.insert(p->h_lead.end(), src, src + tot);
     }
+    p->lead_hash = hash_words(p->h_lead.data(), p->h_lead.size() * sizeof(cplx));
     p->eta = eta; p->conv = conv; p->relFactor = relFactor; p->max_iter = max_iter;
     p->force_iters = force_iters;
     *handle = add_provider(c, p);
@@ -1026,7 +1122,13 @@ static int stage_grid(negf_ctx* c, int m, int contacts, const double* E, const d
 {
     int rc = ensure_mbuffers(c, m, contacts);
     if (rc) return rc;
-    if (E && (rc = upload(c, c->d_E, reinterpret_cast<const cplx*>(E), (size_t)m))) return rc;
+    if (E) {
+        c->h_E_valid = false;
+        if ((rc = upload(c, c->d_E, reinterpret_cast<const cplx*>(E), (size_t)m))) return rc;
+        const cplx* Eh = reinterpret_cast<const cplx*>(E);
+        c->h_E.assign(Eh, Eh + m);
+        c->h_E_valid = true;
+    }
     if (w && (rc = upload(c, c->d_w, reinterpret_cast<const cplx*>(w), (size_t)m))) return rc;
     return NEGF_OK;
 }
@@ -1221,6 +1323,41 @@ done:
     return rc;
 }
 
+// ------------------------------------------------------------ g(E) cache knob
+int negf_set_chain_cache(negf_ctx* c, int max_grids)
+{
+    if (!c || max_grids < 0 || max_grids > 4096) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (max_grids < (int)c->gcache.size()) free_gcache(c);     // shrinking (or switching off) drops every entry
+    c->gcache_max = max_grids;
+    c->gcache.reserve((size_t)max_grids);                      // entries are handed out by pointer: no reallocation later
+    return NEGF_OK;
+}
+
+int negf_chain_cache_clear(negf_ctx* c)
+{
+    if (!c) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    free_gcache(c);
+    c->gcache.reserve((size_t)c->gcache_max);
+    return NEGF_OK;
+}
+
+int negf_chain_cache_stats(negf_ctx* c, long long* hits, long long* misses, long long* entries, long long* bytes)
+{
+    if (!c) return NEGF_EINVAL;
+    long long n = 0, b = 0;
+    for (const auto& e : c->gcache)
+        if (e.valid) { ++n; b += (long long)(e.g_cap * sizeof(cplx) + 2 * e.it_cap * sizeof(int)); }
+    if (hits) *hits = (long long)c->gcache_hits;
+    if (misses) *misses = (long long)c->gcache_misses;
+    if (entries) *entries = n;
+    if (bytes) *bytes = b;
+    return NEGF_OK;
+}
+
 // ------------------------------------------------------------------ diagnostics
 int negf_profile_enable(negf_ctx* c, int on) { if (!c) return NEGF_EINVAL; c->profiling = on != 0; return NEGF_OK; }
 int negf_profile_reset(negf_ctx* c) { if (!c) return NEGF_EINVAL; prof_resolve(c); c->prof.clear(); return NEGF_OK; }
@@ -1231,6 +1368,15 @@ int negf_profile_read(negf_ctx* c, const char* family, double* total_ms, int* la
     auto it = c->prof.find(family);
     if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == c->prof.end() ? 0 : it->second.launches;
+    return NEGF_OK;
+}
+
+int negf_profile_read_flops(negf_ctx* c, const char* family, double* flops_algorithmic, double* flops_mfma_issued)
+{
+    if (!c || !family) return NEGF_EINVAL;
+    auto it = c->prof.find(family);
+    if (flops_algorithmic) *flops_algorithmic = it == c->prof.end() ? 0.0 : it->second.flops_alg;
+    if (flops_mfma_issued) *flops_mfma_issued = it == c->prof.end() ? 0.0 : it->second.flops_mfma;
     return NEGF_OK;
 }
 

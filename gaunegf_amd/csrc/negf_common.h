@@ -84,9 +84,10 @@ struct SigmaProvider {
     // CHAIN1D matrices, concatenated [sum nc^2] each
     cplx *d_alpha = nullptr, *d_Salpha = nullptr, *d_beta = nullptr, *d_Sbeta = nullptr,
          *d_tau = nullptr, *d_Stau = nullptr;
-    // the same six matrices per contact, zero-padded to 64 x 64 ([contact][6][64][64]; nc_max <= 64 only):
-    // operand streams of chain1d_rs_kernel, which then needs no index clamps
-    cplx* d_lead_pad = nullptr;
+    // host copy of alpha | Salpha | beta | Sbeta and its 64-bit hash: what the surface Green's function depends on
+    // besides eta / conv / relFactor / max_iter -- the key of the context's g(E) cache (ChainGEntry)
+    std::vector<cplx> h_lead;
+    unsigned long long lead_hash = 0;
     double eta = 0, conv = 0, relFactor = 0, mix = 0;
     int max_iter = 0, force_iters = -1;
     // job order learned from the previous evaluation of a grid of order_n jobs (chain kernel)
@@ -118,7 +119,37 @@ struct SigmaProvider {
     cplx* d_pre_c = nullptr;       // [m][pre_nc][n*n] or null
 };
 
-struct ProfEntry { double ms = 0; int launches = 0; };
+// One cached evaluation of the 1-D chain fixed point: the final iterates g(E_m) of every (energy, contact) of one
+// launch, with the sweep counts and convergence flags the launch reported.  g depends on the lead cell (alpha, Salpha,
+// beta, Sbeta), eta, conv, relFactor, max_iter (and force_iters) and E -- NOT on F or on the coupling blocks tau
+// (surfG1D.py:256-262; setF refreshes tau only, :319-329) -- so an entry is keyed on exactly those, bitwise, and
+// outlives the provider that filled it: a provider re-created after setF, the t = I variant behind surfG.g(), the two
+// Sigma evaluations of GrLessInt, calculate_transmission + calculate_dos on one grid and SCF cycles at a fixed Fermi
+// level all find it.  A hit runs only Sigma = t g t^H (the last pass of the chain kernel) and is bit-identical to a miss.
+struct ChainGEntry {
+    std::vector<int> nc;
+    std::vector<cplx> lead;
+    unsigned long long lead_hash = 0, E_hash = 0;
+    double eta = 0, conv = 0, relFactor = 0;
+    int max_iter = 0, force_iters = -1;
+    std::vector<cplx> E;
+    cplx* d_g = nullptr;    size_t g_cap = 0;      // [energies][blk_stride]
+    int* d_it = nullptr;    int* d_cv = nullptr;   size_t it_cap = 0;   // [energies][n_contacts]
+    unsigned long long used = 0;
+    bool valid = false;
+};
+
+struct ProfEntry { double ms = 0; int launches = 0; double flops_alg = 0, flops_mfma = 0; };
+
+// Flop accounting of the dense kernels, per kernel family (negf_profile_read_flops): the launchers add, for every
+// launch, the ALGORITHMIC flops (8 per complex multiply-add: 8 M N K per product -- also for a Hermitian product,
+// whose mirrored half the reference computes --, 8 n^3 per inverse) and the flops actually ISSUED to the
+// matrix cores (3 real products per tile and k-step in the 3M form, 16-granular tiles, K padded to the staged
+// K-tile, only the block tiles on and above the diagonal of a Hermitian product).  Per process, like the context
+// not thread-safe; ProfScope attributes the difference across its lifetime to its family.
+struct FlopCount { double alg = 0, mfma = 0; };
+extern FlopCount g_negf_flops;
+inline void negf_count_flops(double alg, double mfma) { g_negf_flops.alg += alg; g_negf_flops.mfma += mfma; }
 
 struct negf_ctx {
     int device = 0;
@@ -156,6 +187,13 @@ struct negf_ctx {
     int contacts_cap = 0;
     cplx* d_E = nullptr;           // staging for host-pointer API
     cplx* d_w = nullptr;
+    std::vector<cplx> h_E;         // host copy of what stage_grid put into d_E (valid while h_E_valid): the g(E) cache
+    bool h_E_valid = false;        //   keys on the energies without a device round trip
+    // g(E) cache of the 1-D chain providers (negf_set_chain_cache)
+    std::vector<ChainGEntry> gcache;
+    int gcache_max = 8;            // entries (evaluated grids) kept, 0 = off
+    size_t gcache_entry_bytes_max = (size_t)4 << 30;
+    unsigned long long gcache_clock = 0, gcache_hits = 0, gcache_misses = 0;
     cplx* d_acc = nullptr;         // [n*n] result staging
     double* d_scal = nullptr;      // [m_cap][8] scalar outputs
     double* d_site = nullptr;      // [batch][n] per-site DOS staging
@@ -178,6 +216,7 @@ struct negf_ctx {
 // negf_profile_read is called.
 struct ProfScope {
     negf_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr;
+    FlopCount f0;
     ProfScope(negf_ctx* ctx, const char* nm);
     ~ProfScope();
 };
@@ -246,8 +285,10 @@ bool chain1d_lds_supported(int nc_max);
 // the kernel then keeps the old iterate in LDS at a lower occupancy)
 size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb);
 // order: launch slot -> job (energy * n_contacts + contact) or null for launch order
+// gcache / gc_mode: see ChainGEntry -- 0 no cache, 1 store the final iterates, 2 load them and only form Sigma
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
-                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order);
+                        const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
+                        cplx* gcache = nullptr, int gc_mode = 0);
 // order[0..count) = jobs by decreasing sweep count of the evaluation that just ran (iters[count])
 bool chain1d_order_supported(int count);
 void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order);

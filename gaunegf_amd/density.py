@@ -251,28 +251,33 @@ def densityComplexN(F, S, g, Emin, mu, N=100, T=TEMPERATURE, showText=True, meth
 
 
 def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATURE, debug=False):
-    """Adaptive contour integration (density.py:750-816)."""
-    broadening, center, r = _contour(Emin, mu, T)
+    """Equilibrium density by ADAPTIVE integration (density.py:750-816): the nested ANT rule refined level by level
+    (2, 6, 18, ... nodes; only the new nodes of a level are evaluated) on the upper half circle through Emin and
+    mu - 10 kT, then -- at T > 0 -- on the real segment mu +- 10 kT that carries the Fermi tail.  Both pieces hand
+    (energies, weights) to GrInt; node -> energy maps and weight products keep the reference's operation order (the
+    captured grids are compared bit for bit, tests/test_grids.py)."""
+    half_width, mid, radius = _contour(Emin, mu, T)
+    quarter_turn = np.pi / 2
 
-    def computePoint(x, w):
-        theta = np.pi / 2 * (x + 1)
-        z = center + r * np.exp(1j * theta)
-        dz = 1j * r * np.exp(1j * theta)
-        weights = (np.pi / 2) * w * dz * fermi(z, mu, T)
-        return GrInt(F, S, g, z, weights)
+    def on_arc(x, w):
+        phase = np.exp(1j * (quarter_turn * (x + 1)))
+        return mid + radius * phase, quarter_turn * w * (1j * radius * phase)
+
+    def on_tail(x, w):
+        return half_width * (x) + mu, half_width * w
+
+    def integral_over(node_map):
+        def level(x, w):
+            z, wz = node_map(x, w)
+            return GrInt(F, S, g, z, wz * fermi(z, mu, T))
+        return integratePointsAdaptiveANT(level, tol=tol, debug=debug)
 
     print('Complex Contour Integration:')
-    lineInt = integratePointsAdaptiveANT(computePoint, tol=tol, debug=debug)
+    total = integral_over(on_arc)
     if T > 0:
         print('Integrating Fermi Broadening:')
-
-        def computePointBroadening(x, w):
-            E = broadening * (x) + mu
-            weights = broadening * w * fermi(E, mu, T)
-            return GrInt(F, S, g, E, weights)
-
-        lineInt += integratePointsAdaptiveANT(computePointBroadening, tol=tol, debug=debug)
-    return (1 + 0j) * np.imag(lineInt) / np.pi
+        total += integral_over(on_tail)
+    return (1 + 0j) * np.imag(total) / np.pi
 
 
 # ------------------------------------------------------------- DOS at one E

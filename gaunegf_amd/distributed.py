@@ -7,8 +7,13 @@ m = r, r+W, r+2W, ... (cyclic, which balances the data-dependent iteration count
 of the self-energy fixed points and the stiffer points near the real axis), every
 rank accumulates its partial N x N sum on its own GPU, and ONE sum all-reduce of
 2 N^2 doubles (RCCL over xGMI; ``backend="nccl"`` is RCCL on ROCm) finishes the
-integral.  Per-energy scalars (T(E), DOS(E)) are combined the same way on a
-zero-filled length-M vector, which is exact (x + 0 == x).
+integral.  Per-energy scalars (T(E), DOS(E)) of the shards are put together by ONE
+all-gather of ceil(M / W) rows per rank (``all_gather_shards``; on the device with the
+nccl backend).  No other collective exists.
+
+``comm_ms_reset()`` / ``comm_ms_total()`` time the collectives themselves (device events
+around the RCCL calls on the stream they are issued on, the host clock for CPU backends),
+so that a multi-GPU bench line can say how much of a step is communication.
 
 Opt-in: call ``enable()`` after ``torch.distributed.init_process_group``; every rank
 must then call GrInt / GrLessInt / calculate_transmission with the same arguments
@@ -17,6 +22,49 @@ must then call GrInt / GrLessInt / calculate_transmission with the same argument
 import numpy as np
 
 _state = {"enabled": False, "group": None, "single_ok": False}
+_comm = {"events": [], "host_ms": 0.0, "calls": 0}
+
+
+def comm_ms_reset():
+    _comm["events"].clear(); _comm["host_ms"] = 0.0; _comm["calls"] = 0
+
+
+def comm_ms_total():
+    """(milliseconds spent in collectives since comm_ms_reset, number of collectives)."""
+    ms = _comm["host_ms"]
+    for a, b in _comm["events"]:
+        b.synchronize()
+        ms += a.elapsed_time(b)
+    return ms, _comm["calls"]
+
+
+class _timed_collective:
+    """Times one collective: device events on the current stream of ``tensor``'s device when it is a device tensor
+    (the stream torch.distributed enqueues RCCL work behind), the host clock otherwise."""
+    def __init__(self, tensor):
+        self.cuda = bool(getattr(tensor, "is_cuda", False))
+        self.dev = tensor.device if self.cuda else None
+
+    def __enter__(self):
+        import time
+        _comm["calls"] += 1
+        if self.cuda:
+            import torch
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.dev))
+        else:
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        import time
+        if self.cuda:
+            import torch
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            _comm["events"].append((self.e0, self.e1))
+        else:
+            _comm["host_ms"] += (time.perf_counter() - self.t0) * 1e3
+        return False
 
 
 def _dist():
@@ -72,7 +120,8 @@ def allreduce_sum(arr):
     backend = dist.get_backend(_state["group"])
     if backend == "nccl":
         t = t.cuda()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
+    with _timed_collective(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
     out = t.cpu().numpy()
     return out.view(np.complex128).reshape(a.shape) if is_c else out.reshape(a.shape)
 
@@ -81,7 +130,8 @@ def allreduce_sum_tensor(t):
     """In-place sum all-reduce of a (device) tensor; the device-resident path of
     bench.py and of large integrals: 2 N^2 doubles, one collective per integral."""
     dist = _dist()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
+    with _timed_collective(t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
     return t
 
 
@@ -118,10 +168,12 @@ def sharded_device_sum(engine, run_dev, E, w):
         engine.warn_if_singular_dev(int(idx.size), "sharded integral", grid_index=idx)
     flat = torch.view_as_real(out)
     if dist.get_backend(_state["group"]) == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_state["group"])
+        with _timed_collective(flat):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_state["group"])
         return out.cpu().numpy()
     host = flat.cpu()
-    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_state["group"])
+    with _timed_collective(host):
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=_state["group"])
     return torch.view_as_complex(host).numpy().copy()
 
 
@@ -154,10 +206,12 @@ def all_gather_shards(part, m, device=None):
         mine = mine.cuda(device) if device is not None else mine.cuda()
     if mine.is_cuda:
         gathered = torch.empty((world, cap) + tuple(tail), dtype=torch.float64, device=mine.device)
-        dist.all_gather_into_tensor(gathered, mine, group=_state["group"])
+        with _timed_collective(mine):
+            dist.all_gather_into_tensor(gathered, mine, group=_state["group"])
     else:
         chunks = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(chunks, mine, group=_state["group"])
+        with _timed_collective(mine):
+            dist.all_gather(chunks, mine, group=_state["group"])
         gathered = torch.stack(chunks)
     g = gathered.cpu().numpy()
     full = np.empty((m,) + tuple(tail), dtype=np.float64)

@@ -66,6 +66,8 @@ class Engine:
         self.last_info = None
         self.last_iters = None
         self.last_converged = None
+        # calls into the hot path and energy points they carried, since the object was made (bench.py --config scf)
+        self.counters = {"calls": 0, "points": 0}
 
     # ------------------------------------------------------------- lifetime
     def close(self):
@@ -97,6 +99,19 @@ class Engine:
 
     def sync(self):
         check(self._lib.negf_sync(self._ctx), "negf_sync")
+
+    def set_chain_cache(self, max_grids):
+        """g(E) cache of the 1-D chain providers: number of evaluated grids kept in HBM (default 8, 0 = off)."""
+        check(self._lib.negf_set_chain_cache(self._ctx, int(max_grids)), "negf_set_chain_cache")
+
+    def chain_cache_clear(self):
+        check(self._lib.negf_chain_cache_clear(self._ctx), "negf_chain_cache_clear")
+
+    def chain_cache_stats(self):
+        """dict(hits, misses, entries, bytes)."""
+        v = [C.c_longlong(0) for _ in range(4)]
+        check(self._lib.negf_chain_cache_stats(self._ctx, *[C.byref(x) for x in v]), "negf_chain_cache_stats")
+        return dict(zip(("hits", "misses", "entries", "bytes"), (int(x.value) for x in v)))
 
     # --------------------------------------------------------------- system
     def set_system(self, F, S):
@@ -213,6 +228,7 @@ class Engine:
     # -------------------------------------------------------------- hot path
     def _grid(self, E, w=None):
         E = np.ascontiguousarray(np.asarray(E).ravel(), dtype=np.complex128)
+        self.counters["calls"] += 1; self.counters["points"] += E.size
         if w is None:
             return E, None
         w = np.ascontiguousarray(np.asarray(w).ravel(), dtype=np.complex128)
@@ -290,14 +306,17 @@ class Engine:
 
     # -------------------------------------------------- device-resident calls
     def gr_int_dev(self, handle, m, E_ptr, w_ptr, out_ptr):
+        self.counters["calls"] += 1; self.counters["points"] += int(m)
         check(self._lib.negf_gr_int_dev(self._ctx, handle, int(m), C.c_void_p(E_ptr), C.c_void_p(w_ptr),
                                         C.c_void_p(out_ptr)), "negf_gr_int_dev")
 
     def gless_int_dev(self, handle, ind, m, E_ptr, w_ptr, out_ptr):
+        self.counters["calls"] += 1; self.counters["points"] += int(m)
         check(self._lib.negf_gless_int_dev(self._ctx, handle, _ind(ind), int(m), C.c_void_p(E_ptr),
                                            C.c_void_p(w_ptr), C.c_void_p(out_ptr)), "negf_gless_int_dev")
 
     def transmission_dev(self, handle, contact_L, contact_R, m, E_ptr, T_ptr, Tspin_ptr=0, spin_block=False):
+        self.counters["calls"] += 1; self.counters["points"] += int(m)
         mode = NEGF_SPIN_BLOCK if spin_block else NEGF_SPIN_RESTRICTED
         check(self._lib.negf_transmission_dev(self._ctx, handle, int(contact_L), int(contact_R), mode, int(m),
                                               C.c_void_p(E_ptr), C.c_void_p(T_ptr),
@@ -334,6 +353,13 @@ class Engine:
         check(self._lib.negf_profile_read(self._ctx, family.encode(), C.byref(ms), C.byref(n)),
               "negf_profile_read")
         return ms.value, n.value
+
+    def profile_read_flops(self, family):
+        """(algorithmic flops, flops issued to the matrix cores) of the family's launches since profile_reset."""
+        a = C.c_double(0.0); m = C.c_double(0.0)
+        check(self._lib.negf_profile_read_flops(self._ctx, family.encode(), C.byref(a), C.byref(m)),
+              "negf_profile_read_flops")
+        return a.value, m.value
 
     def selftest_mfma(self):
         err = C.c_double(-1.0)

@@ -10,6 +10,8 @@ fixed point over the 6 in-plane directions and the per-atom assembly
 (surfGBethe.py:958-1108, 512-527) run in one HIP kernel, one workgroup per
 (energy, contact); inside GrInt/GrLessInt the 9x9 blocks are consumed on the device.
 """
+import os
+
 import numpy as np
 
 from .config import ETA, TEMPERATURE, SURFACE_GREEN_CONVERGENCE, FERMI_CALCULATION_TOL, ENERGY_MIN, \
@@ -30,10 +32,23 @@ _EXPECTED_KEYS = ['ne', 'es', 'ep', 'edd', 'edt', 'sss', 'sps', 'pps', 'ppp', 's
 # --------------------------------------------------------------------------- #
 # parameter file and Slater-Koster blocks (host, setup time)
 # --------------------------------------------------------------------------- #
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def lattice_file(name):
+    """Path (without the ``.bethe`` extension, as ``latFile`` wants it) of a parameter table shipped with the package:
+    ``Au``, ``Au2`` -- the reference keeps them in its checkout root and opens them relative to the working directory."""
+    return os.path.join(DATA_DIR, name)
+
+
 def read_bethe_params(filename):
     """Parse ``<filename>.bethe`` (``key = value`` lines, 25 keys) into
-    (ne, Edict[eV], Vdict[eV], Sdict, H0) -- surfGBethe.py:301-355."""
+    (ne, Edict[eV], Vdict[eV], Sdict, H0) -- surfGBethe.py:301-355.  A bare name that is not found relative to the
+    working directory (where the reference looks) is looked up among the tables shipped in gaunegf_amd/data."""
     params = {}
+    if not os.path.exists(filename + '.bethe') and not os.path.dirname(filename) and \
+            os.path.exists(lattice_file(filename) + '.bethe'):
+        filename = lattice_file(filename)
     with open(filename + '.bethe', 'r') as f:
         for line in f:
             if not line.strip():

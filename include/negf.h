@@ -88,6 +88,11 @@ int negf_sigma_const(negf_ctx* ctx, int n_contacts, const double* sigma_c128, in
  * matrices alpha,Salpha,beta,Sbeta,tau,Stau (concatenated in contact order).
  * eta/conv/relFactor/max_iter default in the reference to ETA=1e-6 (config.py:9),
  * 1e-5 (config.py:15), 0.1 (config.py:16), 2000 (surfG1D.py:265).
+ * Pivoting inside the fixed point's inverses (n_c <= 64 kernel): partial pivoting by LAPACK's izamax metric
+ * |re| + |im|, compared on the HIGH 32-bit word of the double (sign, exponent, 20 mantissa bits); candidates whose
+ * metrics agree to 2^-20 relative count as tied and the lowest row wins, as LAPACK's exact ties do.  (The dense
+ * inverses of the hot path compare 36 mantissa bits.)  A different pivot among near-equal candidates changes
+ * rounding only: parity with the reference is 1e-10 at a fixed trip count (observed 1e-13).
  * force_iters >= 0 runs exactly that many sweeps (parity at fixed trip count);
  * pass -1 for the reference's data-dependent stopping rule. */
 int negf_sigma_chain1d(negf_ctx* ctx, int n_contacts, const int* nc, const int* inds,
@@ -186,12 +191,35 @@ int negf_last_info(negf_ctx* ctx, int m, int* info);
  * surfG1D.py:271-288, surfGBethe.py:1004-1022); zeros / ones for providers without a loop */
 int negf_last_iters(negf_ctx* ctx, int handle, int m, int* iters, int* converged);
 
+/* ------------------------------------------ surface Green's function cache
+ * The decimation fixed point g(E) of a 1-D chain lead (surfG1D.py:223-295) depends on the lead cell (alpha, Salpha,
+ * beta, Sbeta), eta, conv, relFactor, max_iter and E -- not on F and not on the coupling blocks tau (:256-262; setF
+ * refreshes tau only, :319-329).  The reference recomputes it inside every vmapped closure (integrate.py:168-171) and
+ * twice per energy in GrLessInt (:201-204).  The context keeps the final iterates of the last `max_grids` launches of
+ * the n_c <= 64 chain kernel in HBM (n_contacts * n_c^2 * 16 bytes per energy), keyed BITWISE on those inputs and on
+ * the energy list of the launch; a launch that finds its key only forms Sigma = t g t^H with the provider's CURRENT
+ * tau -- the last pass of the same kernel, so a hit equals a miss bit for bit, sweep counts and flags included.  The
+ * key outlives providers: one re-created after setF, or the t = I variant behind surfG.g(), hits entries of its
+ * predecessor.  Default: 8 grids; 0 switches the cache off and frees it (bench.py's headline runs cold that way).
+ * Launches whose g would exceed 4 GB are not cached.  The *_dev entry points download their energy list (16 bytes
+ * per point, one stream synchronisation) to form the key while the cache is on. */
+int negf_set_chain_cache(negf_ctx* ctx, int max_grids);
+int negf_chain_cache_clear(negf_ctx* ctx);
+/* counters since negf_create; entries / bytes currently held (any pointer may be NULL) */
+int negf_chain_cache_stats(negf_ctx* ctx, long long* hits, long long* misses, long long* entries, long long* bytes);
+
 /* ------------------------------------------------------------- diagnostics */
 /* hipEvent timing of the library's own kernels, per kernel family
  * ("inverse", "assemble", "accumulate", "zgemm", "trace", "chain1d", "bethe"). */
 int negf_profile_enable(negf_ctx* ctx, int on);
 int negf_profile_reset(negf_ctx* ctx);
 int negf_profile_read(negf_ctx* ctx, const char* family, double* total_ms, int* launches);
+/* flops of the family's launches since negf_profile_reset, two ways: ALGORITHMIC (8 per complex multiply-add: 8 M N K
+ * per dense product, 8 n^3 per inverse -- what the reference's solve / matmul would be charged) and ISSUED
+ * to the matrix cores (the kernels use the 3-real-product form of a complex product, compute 16-granular tiles, skip
+ * the lower block tiles of Hermitian products; pivot steps and other vector work are not matrix-core flops).  Only
+ * the second may be divided by the FP64 MFMA peak and called utilisation.  Families: "inverse", "zgemm". */
+int negf_profile_read_flops(negf_ctx* ctx, const char* family, double* flops_algorithmic, double* flops_mfma_issued);
 /* choose the inverse kernel: 0 = auto, 1 = unblocked Gauss-Jordan (any n),
  * 2 = blocked Gauss-Jordan with FP64 MFMA trailing updates */
 int negf_set_inverse_algo(negf_ctx* ctx, int algo);

@@ -133,7 +133,7 @@ def c4():
     N = 800
     F, S = random_system(N, 4)
     coords, orbMap, orbTyp = _bethe_contacts(N)
-    lat = os.path.join(ROOT, "tests", "golden", "Au")
+    lat = os.path.join(ROOT, "gaunegf_amd", "data", "Au")
     t0 = time.perf_counter()
     g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
     t_setup = time.perf_counter() - t0
@@ -168,7 +168,7 @@ def c4b():
     real-axis energies, free-running fixed points (bulk 12 directions, then surface 6 directions)."""
     import os
     from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix, gen_neighbors, surfGBAt
-    here = os.path.join(ROOT, "tests", "golden", "Au")
+    here = os.path.join(ROOT, "gaunegf_amd", "data", "Au")
     ne, Ed, Vd, Sd, H0 = read_bethe_params(here)
     dirs = gen_neighbors(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.2, 0.0]))
     Sl = [construct_sk_matrix(Sd, d) for d in dirs]; Vl = [construct_sk_matrix(Vd, d) for d in dirs]

@@ -1,7 +1,7 @@
 """Random sizes / batch sizes through the blocked inverses (GrBatch), each result checked by its residual G A = I:
 edge cases of the window pairs, sub-panel pairs, narrow last windows, the eight-wave / lean update selection."""
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import random_system
 from gaunegf_amd.integrate import GrBatch
 from gaunegf_amd.surfGTester import surfGTest

@@ -1,7 +1,7 @@
 """Random sizes through the dense-product paths (G Gamma G^H as a Hermitian product, the transmission's one and a half
 products, both zgemm kernels, ragged block edges, odd / even block counts) against the numpy oracle."""
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from tests.helpers import random_system, const_sigma_pair, rel_fro
 from gaunegf_amd.integrate import GrLessInt

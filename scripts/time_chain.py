@@ -1,7 +1,8 @@
 """Time the 1-D chain self-energy kernel (C3 contact: n_c = 50, eta = 1e-4): kernel time from the
 library's hipEvents (negf_profile_*), not the host call (which also scatters and downloads Sigma)."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault("NEGF_CHAIN_CACHE", "0")      # time the fixed point, not the g(E) cache
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts.bench_configs import _c3_system
 from gaunegf_amd.engine import get_engine
 F, S, g, ref = _c3_system()

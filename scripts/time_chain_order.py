@@ -1,7 +1,8 @@
 """What the predicted job order is worth on a NEW grid: the C3 leads, a 2000-point grid A, then a 1900-point grid B moved by
 0.013 eV -- B evaluated by a fresh provider (launch order) against B evaluated after A (order predicted from A)."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault("NEGF_CHAIN_CACHE", "0")      # time the fixed point, not the g(E) cache
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from gaunegf_amd.surfG1D import surfG
 F, S, inds, kw = bench.c3_system(500, 50, 1e-4)

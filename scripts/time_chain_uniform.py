@@ -2,7 +2,8 @@
 one per resident slot (3 per CU), no tail: kernel time / sweeps = time per sweep and slot; compare with the
 free-running C3 grid (scripts/time_chain.py), where job lengths vary from ~100 to 2000 sweeps."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; os.environ.setdefault("NEGF_CHAIN_CACHE", "0")      # time the fixed point, not the g(E) cache
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts.bench_configs import _c3_system
 from gaunegf_amd.engine import get_engine
 F, S, g, ref = _c3_system()

@@ -16,7 +16,7 @@ if cfg == "c4":
     N = 800
     F, S = bench.random_system(N, 4)
     coords, orbMap, orbTyp = bench._bethe_contacts(N)
-    lat = os.path.join(bench.ROOT, "tests", "golden", "Au")
+    lat = os.path.join(bench.ROOT, "gaunegf_amd", "data", "Au")
     g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
     Ec, wc = DN.contour_grid(-8.0, 0.0, 486, 0.0)
     Er, wr = DN.real_axis_grid(-1e6, -8.0, 256, 0.0)

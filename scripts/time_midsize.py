@@ -1,7 +1,7 @@
 """Time the dense inverse path (constant Sigma, GrInt, 1000 energies, device-resident) at a few sizes:
 kernel time of the inverse family from the library's hipEvents."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.helpers import random_system
 from gaunegf_amd.engine import get_engine

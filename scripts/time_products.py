@@ -1,7 +1,7 @@
 """Time the dense complex products (G Gamma G^H: two zgemm per energy) at a few sizes through GrLessInt with
 the dense-Gamma path forced; kernel time of the zgemm family from the library's hipEvents."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.helpers import random_system
 from gaunegf_amd.engine import get_engine

@@ -3,7 +3,7 @@ of other allocations alive: what a per-call provider used to add to calculate_tr
 import sys, time, numpy as np
 import torch
 torch.zeros(1, device='cuda')
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import random_system
 from gaunegf_amd.engine import get_engine
 from gaunegf_amd.matTools import formSigma

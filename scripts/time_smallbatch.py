@@ -2,7 +2,7 @@
 configurations leave one GPU: C4 sharded 8 ways = 61 contour matrices of N = 800, C5 = 128 matrices of N = 1000,
 beside the full-batch figures.  Kernel time of the inverse family from the library's hipEvents."""
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.helpers import random_system
 from gaunegf_amd.engine import get_engine

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import random_system
 from gaunegf_amd.surfGTester import surfGTest
 from gaunegf_amd.transport import SigmaCalculator, calculate_transmission

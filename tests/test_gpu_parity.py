@@ -553,12 +553,16 @@ def test_chain1d_order_predicted_for_new_grids(engine):
     grids = [np.linspace(-1.5, 1.5, 37), np.linspace(-1.4, 1.6, 64), np.linspace(-1.5, 1.5, 37) + 0.01,
              np.linspace(-0.2, 0.2, 5), np.linspace(-1.5, 1.5, 37), np.linspace(-1.6, 1.4, 130) + 0.05j]
     _, _, g_seq, _ = _chain_system(3 * nc, nc, 77, 1e-3)
-    for E in grids:
-        _, _, g_fresh, _ = _chain_system(3 * nc, nc, 77, 1e-3)
-        sig0, it0, cv0 = g_fresh.sigma_batch(E)                 # first evaluation of a provider: launch order
-        sig1, it1, cv1 = g_seq.sigma_batch(E)                   # order predicted from the grid before
-        assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
-        assert it1.max() > it1.min()                            # (the jobs do differ in length)
+    engine.set_chain_cache(0)                                   # every evaluation runs the fixed point (no g(E) cache hits)
+    try:
+        for E in grids:
+            _, _, g_fresh, _ = _chain_system(3 * nc, nc, 77, 1e-3)
+            sig0, it0, cv0 = g_fresh.sigma_batch(E)             # first evaluation of a provider: launch order
+            sig1, it1, cv1 = g_seq.sigma_batch(E)               # order predicted from the grid before
+            assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
+            assert it1.max() > it1.min()                        # (the jobs do differ in length)
+    finally:
+        engine.set_chain_cache(8)
 
 
 @pytest.mark.parametrize("nc,eta", [(50, 1e-4), (64, 1e-3), (72, 1e-3)])
@@ -690,7 +694,7 @@ def test_perfect_wire_closed_form(engine):
 # --------------------------------------------------------------------------- #
 def _bethe_atom(name="Au"):
     from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix, gen_neighbors, surfGBAt
-    here = os.path.join(os.path.dirname(__file__), "golden", name)
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaunegf_amd", "data", name)
     ne, Ed, Vd, Sd, H0 = read_bethe_params(here)
     dirs = gen_neighbors(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.2, 0.0]))
     Sl = [construct_sk_matrix(Sd, d) for d in dirs]
@@ -791,7 +795,7 @@ def test_bethe_contact_assembly_and_integrals(engine, name):
     N = 60
     coords, orbMap, orbTyp = _bethe_device(name, N)
     F, S = random_system(N, 77)
-    lat = os.path.join(os.path.dirname(__file__), "golden", name)
+    lat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaunegf_amd", "data", name)
     g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
     g.force_iters = 30
     Xi = g.Xi if g.Sdict['sss'] == 0 else None
@@ -825,7 +829,7 @@ def test_bethe_contact_assembly_given_device_surface(engine, spin):
     N = 60
     coords, orbMap, orbTyp = _bethe_device("Au", N)
     F, S = random_system(N, 78)
-    lat = os.path.join(os.path.dirname(__file__), "golden", "Au")
+    lat = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gaunegf_amd", "data", "Au")
     g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0, spin=spin)
     g.force_iters = 20
     for at in g.gList:
@@ -1057,9 +1061,18 @@ def test_config_C3_free_running_at_the_sweep_cap(engine):
     at_cap = it.max(axis=1) >= 2000
     assert at_cap.sum() >= 6 and (~at_cap).sum() >= 2, it.max(axis=1)
     sub = np.concatenate([probe[at_cap][:6], probe[~at_cap][:2]])
-    sig, iters, cv = g_dev.sigma_batch(E[sub])
-    sig2, iters2, cv2 = g_dev.sigma_batch(E[sub])                 # learned (longest-first) launch order
+    engine.set_chain_cache(0)                                     # both evaluations run the fixed point
+    try:
+        sig, iters, cv = g_dev.sigma_batch(E[sub])
+        sig2, iters2, cv2 = g_dev.sigma_batch(E[sub])             # learned (longest-first) launch order
+    finally:
+        engine.set_chain_cache(8)
     assert np.array_equal(iters, iters2) and np.array_equal(cv, cv2) and np.array_equal(sig, sig2)
+    sig3, iters3, cv3 = g_dev.sigma_batch(E[sub])                 # fills the g(E) cache ...
+    sig4, iters4, cv4 = g_dev.sigma_batch(E[sub])                 # ... and is served from it: the same bits again
+    assert engine.chain_cache_stats()["hits"] >= 1
+    for s_, i_, c_ in ((sig3, iters3, cv3), (sig4, iters4, cv4)):
+        assert np.array_equal(iters, i_) and np.array_equal(cv, c_) and np.array_equal(sig, s_)
     for k, e in enumerate(E[sub]):
         ref = g_ref.sigmaTot(e)
         for c in (0, 1):
@@ -1078,7 +1091,7 @@ def test_config_C4_shape(engine):
     N = 800
     F, S = random_system(N, 4)
     coords, orbMap, orbTyp = _bethe_device("Au", N)
-    lat = os.path.join(os.path.dirname(__file__), "golden", "Au")
+    lat = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gaunegf_amd", "data", "Au")
     g = surfGB.from_arrays(F, S, [[1, 2, 3], [4, 5, 6]], orbMap, orbTyp, coords, latFile=lat, eta=1e-6, fermi=0.0)
     g.force_iters = 30
     Xi = g.Xi if g.Sdict['sss'] == 0 else None

@@ -179,7 +179,7 @@ def test_bethe_invariants():
     # Retarded convention of this code path is E - i*eta, so Im(sigma) >= 0 on the diagonal.
     from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix, gen_neighbors
     import os
-    ref = os.path.join(os.path.dirname(__file__), "golden", "Au")
+    ref = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gaunegf_amd", "data", "Au")
     ne, Ed, Vd, Sd, H0 = read_bethe_params(ref)
     dirs = gen_neighbors(np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
     Sl = [construct_sk_matrix(Sd, d) for d in dirs]
@@ -210,7 +210,7 @@ def test_bethe_setup_and_loops_vs_reference_numpy_twin(golden_bethe, name):
     import os
     from gaunegf_amd.surfGBethe import read_bethe_params, gen_neighbors, construct_sk_matrix, surfGBAt
     g = golden_bethe
-    here = os.path.join(os.path.dirname(__file__), "golden", name)
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaunegf_amd", "data", name)
     ne, Ed, Vd, Sd, H0 = read_bethe_params(here)
     assert ne == float(g[f"{name}_ne"]) and np.array_equal(H0, g[f"{name}_H0"])
     for tag, d in (("E", Ed), ("V", Vd), ("S", Sd)):
@@ -310,7 +310,7 @@ def test_slater_koster_self_tests(name):
     of the d-d block, p-d and d-d sigma / delta limits, s-p antisymmetry and conserved s-p magnitude."""
     import os
     from gaunegf_amd.surfGBethe import read_bethe_params, construct_sk_matrix
-    _, _, Vd, Sd, _ = read_bethe_params(os.path.join(os.path.dirname(__file__), "golden", name))
+    _, _, Vd, Sd, _ = read_bethe_params(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaunegf_amd", "data", name))
     for P in (Vd, Sd):
         M = construct_sk_matrix(P, [1, 0, 0])
         np.testing.assert_almost_equal(M[0, 8], 0.0)                                  # dxy along x
