@@ -393,7 +393,7 @@ def worker_c3(args):
     # Sigma = t g t^H; bit-identical result (asserted); NOT the headline
     warm = None
     if world == 1:
-        eng.set_chain_cache(8)
+        eng.set_chain_cache(512)
         step(); fence()
         eng.profile(True); eng.profile_reset()
         t1 = time.perf_counter()
@@ -709,20 +709,35 @@ def worker_scf(args):
     eng = get_engine()
     names = [x for x in args.scf_systems.split(",") if x]
     out_sys = []
+    # host numpy of the step (eigenvalues of S^-1 F, Lowdin occupations: the reference's own host work, scfE.py:460-468,
+    # density.py:822): BLAS threads limited to this process's CPU share -- the box reports 256 CPUs to OpenBLAS but
+    # schedules one GPU's share of them, and 256 BLAS threads on that turn a 200 x 200 solve into 90 ms
+    limits = _blas_limits()
+    blas_ctx = limits(limits=max(1, min(host_cpus(), int(os.environ.get("NEGF_BENCH_CPU_WORKERS", "16"))))) if limits else None
     for name in names:
         label, F, S, g, make_ref, ne, Eminf = _scf_system(name)
         qV, T, tol = 0.1, 300.0, 1e-4
 
+        fixed = {"mu": None}
+
         def new_step(gobj):
             n = NEGFE(F, S, gobj, ne=ne, spin='r', T=T, Eminf=Eminf)
             n.setIntegralLimits(tol=tol, Emin=None)            # adaptive integrals everywhere; Emin from the DOS
-            n.setVoltage(qV, fermiMethod='muller')             # Fermi level searched (updFermi), bias window open
+            if fixed["mu"] is None:
+                n.setVoltage(qV, fermiMethod='muller')         # Fermi level searched (updFermi), bias window open
+            else:
+                n.setVoltage(qV, fermi=fixed["mu"])            # Fermi level given: the cycles of an SCF run at fixed mu
             return n
         sink = io.StringIO()
         variants = [("", {})]
         if name == "chain":
-            variants = [("cache_off", {"cache": 0}), ("cache_on", {"cache": 8})]
+            # with a Fermi search every probe moves the contour (and, for leads defined by their own cell, the lead
+            # itself: surfG1D.py:331-342), so the g(E) cache has nothing to reuse; at a FIXED Fermi level -- the cycles
+            # of an SCF run that only update F -- every grid of a cycle repeats
+            variants = [("fermi_search/cache_off", {"cache": 0}), ("fermi_search/cache_on", {"cache": 512}),
+                        ("fixed_fermi/cache_off", {"cache": 0, "mu": 0.05}), ("fixed_fermi/cache_on", {"cache": 512, "mu": 0.05})]
         for vname, opt in variants:
+            fixed["mu"] = opt.get("mu")
             if "cache" in opt:
                 eng.set_chain_cache(0); eng.set_chain_cache(opt["cache"])
             with contextlib.redirect_stdout(sink):
@@ -767,7 +782,7 @@ def worker_scf(args):
                 rec["cpu_oracle_replay_ms"] = cpu_dt * 1e3
                 assert rec["parity_rel_fro_P_vs_oracle_replay"] < 1e-8, rec
             out_sys.append(rec)
-    eng.set_chain_cache(0); eng.set_chain_cache(8)
+    eng.set_chain_cache(0); eng.set_chain_cache(512)
     head = out_sys[0]
     line = {"metric": "density-matrix wall time, one NEGFE.FockToP step (adaptive contour + real axis + Muller Fermi search + bias window)",
             "value": head["wall_ms_per_step"], "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),

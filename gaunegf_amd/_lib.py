@@ -47,6 +47,7 @@ SIGNATURES = {
     "negf_sigma_free": (C.c_int, [_vp, C.c_int]),
     "negf_sigma_eval": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "negf_gr_int": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "negf_gr_int_seg": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "negf_gless_int": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "negf_gr_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "negf_transmission": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "negf_last_info": (C.c_int, [_vp, C.c_int, _vp]),
     "negf_last_iters": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "negf_set_chain_cache": (C.c_int, [_vp, C.c_int]),
+    "negf_set_chain_cache_bytes": (C.c_int, [_vp, C.c_longlong]),
     "negf_chain_cache_clear": (C.c_int, [_vp]),
     "negf_chain_cache_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                          C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -67,6 +69,7 @@ SIGNATURES = {
     "negf_profile_read_flops": (C.c_int, [_vp, C.c_char_p, _dp, _dp]),
     "negf_set_inverse_algo": (C.c_int, [_vp, C.c_int]),
     "negf_set_gamma_algo": (C.c_int, [_vp, C.c_int]),
+    "negf_set_small_algo": (C.c_int, [_vp, C.c_int]),
     "negf_selftest_mfma": (C.c_int, [_vp, _dp]),
 }
 

@@ -1428,7 +1428,7 @@ __global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __re
 }
 
 template <int NBI, int RPT>
-void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
+void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp)
 {
     using C = GjCfg<NBI, 1, RPT, PW, PW>;
     const size_t smem = (size_t)(2 * PW * NBI + 2 * NBI * WIN) * sizeof(cplx);      // candidate rows + Q of two sub-panels
@@ -1520,18 +1520,13 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     if (groups == 1) {
         chain(st, 0, nb);
     } else {
-        constexpr int MAXG = 4, MAXDEV = 16;
-        // side streams and fork / join events of the CURRENT device (a process may drive several contexts on
-        // several devices; streams and events belong to the device they were created on)
-        struct Side { hipStream_t s[MAXG - 1]; hipEvent_t fork, join[MAXG - 1]; bool ok; };
-        static Side per_dev[MAXDEV] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= MAXDEV) { chain(st, 0, nb); return; }
-        Side& sd = per_dev[dev];
+        // side streams and fork / join events belong to the CONTEXT (created on its device at first use, destroyed with
+        // it): two contexts never record the same events
+        if (!sdp) { chain(st, 0, nb); return; }
+        GjSideStreams& sd = *sdp;
         if (!sd.ok) {
             bool good = hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) == hipSuccess;
-            for (int g = 0; g < MAXG - 1; ++g) {
+            for (int g = 0; g < GjSideStreams::MAXG - 1; ++g) {
                 good = good && hipStreamCreateWithFlags(&sd.s[g], hipStreamNonBlocking) == hipSuccess;
                 good = good && hipEventCreateWithFlags(&sd.join[g], hipEventDisableTiming) == hipSuccess;
             }
@@ -1595,7 +1590,7 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // In-place reduction of A with B as scratch; the inverses are gathered into B.
 // piv: [nb][2][n] ints of pivot bookkeeping (used by the large-matrix path).
 // Returns true: the result is in B.
-bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info)
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* side)
 {
     // single-workgroup kernel up to 256 rows (its 32-column panel configuration); above, the windowed
     // path with 16-column sub-panels is faster (measured on MI355X, ms per 1000 matrices: n = 260 9.3 vs
@@ -1610,11 +1605,11 @@ bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, siz
     // sub-panels of 16 columns up to n = 1024 (measured on MI355X, 1000 matrices: n = 500 46.2 -> 41.1 ms,
     // n = 1000 296 -> 257 ms against sub-panels of 8: half as many passes over the 64-column window)
     switch (gj_large_pick(n)) {
-    case 1: gj_large_launch<16, 2>(st, n, nb, A, B, stride, piv, info); return true;
-    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info); return true;
-    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info); return true;
-    case 4: gj_large_launch<16, 1>(st, n, nb, A, B, stride, piv, info); return true;
-    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info); return true;
+    case 1: gj_large_launch<16, 2>(st, n, nb, A, B, stride, piv, info, side); return true;
+    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info, side); return true;
+    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info, side); return true;
+    case 4: gj_large_launch<16, 1>(st, n, nb, A, B, stride, piv, info, side); return true;
+    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info, side); return true;
     default: return false;
     }
 }

@@ -3,6 +3,7 @@
 // host here; there is no CPU fallback (negf_create fails without a GPU).
 #include "negf_common.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <new>
 
@@ -48,6 +49,8 @@ static void prof_resolve(negf_ctx* c)
 
 namespace {
 
+int wait_stream(negf_ctx* c);
+
 template <typename T>
 int dev_alloc(T** p, size_t count)
 {
@@ -73,8 +76,7 @@ int download(negf_ctx* c, T* dst, const T* src, size_t count)
 {
     if (count == 0) return NEGF_OK;
     NEGF_HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
-    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return NEGF_OK;
+    return wait_stream(c);
 }
 
 void free_provider(SigmaProvider* p)
@@ -82,7 +84,7 @@ void free_provider(SigmaProvider* p)
     if (!p) return;
     dev_free(p->d_const_c); dev_free(p->d_const_tot); dev_free(p->d_hbase); dev_free(p->d_const_blk);
     dev_free(p->d_inds); dev_free(p->d_nc); dev_free(p->d_blk_off); dev_free(p->d_inds_off);
-    dev_free(p->d_n_atoms); dev_free(p->d_atom_off);
+    dev_free(p->d_n_atoms); dev_free(p->d_atom_off); dev_free(p->d_pos);
     dev_free(p->d_alpha); dev_free(p->d_Salpha); dev_free(p->d_beta); dev_free(p->d_Sbeta);
     dev_free(p->d_tau); dev_free(p->d_Stau);
     dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
@@ -95,7 +97,8 @@ void free_workspace(negf_ctx* c)
 {
     dev_free(c->d_A); dev_free(c->d_T1); dev_free(c->d_T2); dev_free(c->d_blk);
     dev_free(c->d_ipiv); dev_free(c->d_site); dev_free(c->d_scratch); dev_free(c->d_gsmall);
-    c->batch = 0; c->blk_cap = 0; c->scratch_cap = 0; c->gsmall_cap = 0;
+    dev_free(c->d_small_part);
+    c->batch = 0; c->blk_cap = 0; c->scratch_cap = 0; c->gsmall_cap = 0; c->small_part_cap = 0;
 }
 
 void free_mbuffers(negf_ctx* c)
@@ -142,7 +145,7 @@ const cplx* host_energies(negf_ctx* c, const cplx* E_dev, int nb, std::vector<cp
 ChainGEntry* gcache_lookup(negf_ctx* c, const SigmaProvider* p, const cplx* Eh, int nb, bool* hit)
 {
     *hit = false;
-    if (c->gcache_max <= 0 || !Eh || nb <= 0 || p->h_lead.empty()) return nullptr;
+    if (c->gcache_max <= 0 || !Eh || nb <= 0 || !p->h_lead) return nullptr;
     const size_t g_elems = (size_t)nb * p->blk_stride, it_elems = (size_t)nb * p->n_contacts;
     if (g_elems * sizeof(cplx) > c->gcache_entry_bytes_max) return nullptr;
     const unsigned long long eh = hash_words(Eh, (size_t)nb * sizeof(cplx));
@@ -151,19 +154,44 @@ ChainGEntry* gcache_lookup(negf_ctx* c, const SigmaProvider* p, const cplx* Eh, 
         if (e.eta != p->eta || e.conv != p->conv || e.relFactor != p->relFactor || e.max_iter != p->max_iter ||
             e.force_iters != p->force_iters || e.nc != p->nc) continue;
         if (std::memcmp(e.E.data(), Eh, (size_t)nb * sizeof(cplx)) != 0) continue;
-        if (e.lead.size() != p->h_lead.size() || std::memcmp(e.lead.data(), p->h_lead.data(), e.lead.size() * sizeof(cplx)) != 0) continue;
+        if (e.lead != p->h_lead && (e.lead->size() != p->h_lead->size() ||
+                                    std::memcmp(e.lead->data(), p->h_lead->data(), e.lead->size() * sizeof(cplx)) != 0)) continue;
         e.used = ++c->gcache_clock;
         ++c->gcache_hits;
         *hit = true;
         return &e;
     }
     ++c->gcache_misses;
+    // room for the new entry: a free slot while the cache is below its entry and byte limits, else the least
+    // recently used entries go -- one whose buffers are large enough is reused as it is
+    auto bytes_of = [](const ChainGEntry& e) { return e.g_cap * sizeof(cplx) + 2 * e.it_cap * sizeof(int); };
+    const size_t need_b = g_elems * sizeof(cplx) + 2 * it_elems * sizeof(int);
+    size_t held = 0;
+    for (const auto& e : c->gcache) held += bytes_of(e);
     ChainGEntry* v = nullptr;
-    if ((int)c->gcache.size() < c->gcache_max) { c->gcache.emplace_back(); v = &c->gcache.back(); }
-    else for (auto& e : c->gcache) if (!v || !e.valid || (v->valid && e.used < v->used)) v = &e;
-    v->valid = false;
+    for (auto& e : c->gcache) if (!e.valid && e.g_cap >= g_elems && e.it_cap >= it_elems) { v = &e; break; }   // an invalidated entry that fits
+    bool synced = false;
+    while (!v) {
+        int with_buffers = 0;
+        ChainGEntry *lru = nullptr, *empty = nullptr;
+        for (auto& e : c->gcache) {
+            if (!e.d_g) { if (!empty) empty = &e; continue; }
+            ++with_buffers;
+            if (!lru || (!e.valid && lru->valid) || (e.valid == lru->valid && e.used < lru->used)) lru = &e;
+        }
+        if (with_buffers < c->gcache_max && held + need_b <= c->gcache_bytes_max) {
+            if (!empty) { c->gcache.emplace_back(); empty = &c->gcache.back(); }     // (capacity reserved: no reallocation)
+            v = empty;
+            break;
+        }
+        if (!lru) return nullptr;                                                    // larger than the whole budget
+        lru->valid = false;
+        if (lru->g_cap >= g_elems && lru->it_cap >= it_elems) { v = lru; break; }    // taken over as it is
+        if (!synced) { (void)hipStreamSynchronize(c->stream); synced = true; }       // earlier kernels may still read it
+        held -= bytes_of(*lru);
+        free_gentry(*lru);
+    }
     if (g_elems > v->g_cap || it_elems > v->it_cap) {
-        (void)hipStreamSynchronize(c->stream);              // kernels of earlier calls may still read the old buffers
         free_gentry(*v);
         if (dev_alloc(&v->d_g, g_elems) || dev_alloc(&v->d_it, it_elems) || dev_alloc(&v->d_cv, it_elems)) { free_gentry(*v); return nullptr; }
         v->g_cap = g_elems; v->it_cap = it_elems;
@@ -199,7 +227,10 @@ int auto_batch(negf_ctx* c, int m)
 
 int ensure_workspace(negf_ctx* c, int m, int blk_stride, int min_batch = 1)
 {
-    const int want = std::max(auto_batch(c, m), min_batch);
+    // (the workspace in place already covers the grid: no hipMemGetInfo, which costs more than a small integral)
+    const int covers = (c->transmission_seen ? 2 : 1) * std::max(m, 1);
+    const int want = (c->batch_user == 0 && c->batch >= std::min(covers, 4096) && c->batch >= min_batch)
+                         ? c->batch : std::max(auto_batch(c, m), min_batch);
     if (want > c->batch) {
         free_workspace(c);
         const size_t n2 = (size_t)c->n * c->n;
@@ -221,6 +252,77 @@ int ensure_workspace(negf_ctx* c, int m, int blk_stride, int min_batch = 1)
         c->blk_cap = need_blk;
     }
     return NEGF_OK;
+}
+
+// Wait for the context's stream at the end of a host-pointer call.  hipStreamSynchronize parks the thread and is woken
+// by an interrupt -- tens of microseconds after the GPU is done, as much as a small integral itself takes -- so the
+// stream is POLLED for the first 2 ms (an SCF-sized call is over long before) and only then handed to the blocking wait.
+// NEGF_SYNC_SPIN=0: always block.
+int wait_stream(negf_ctx* c)
+{
+    static int spin = -1;
+    if (spin < 0) { const char* e = getenv("NEGF_SYNC_SPIN"); spin = e ? atoi(e) : 1; }
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return NEGF_OK;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+    }
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return NEGF_OK;
+}
+
+int ensure_blk(negf_ctx* c, size_t elems)
+{
+    if (elems <= (size_t)c->blk_cap) return NEGF_OK;
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+    dev_free(c->d_blk); c->blk_cap = 0;
+    int rc = dev_alloc(&c->d_blk, elems);
+    if (rc) return rc;
+    c->blk_cap = (int)elems;
+    return NEGF_OK;
+}
+
+int ensure_pinned(negf_ctx* c, size_t bytes)
+{
+    if (bytes <= c->h_pin_cap) return NEGF_OK;
+    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));           // copies from / into the old buffer
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
+    if (c->gj_side.ok) {
+        (void)hipEventDestroy(c->gj_side.fork);
+        for (int g = 0; g < GjSideStreams::MAXG - 1; ++g) { (void)hipStreamDestroy(c->gj_side.s[g]); (void)hipEventDestroy(c->gj_side.join[g]); }
+        c->gj_side.ok = false;
+    }
+    const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 20);
+    void* q = nullptr;
+    if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return NEGF_ENOMEM; }
+    c->h_pin = static_cast<unsigned char*>(q); c->h_pin_cap = cap;
+    return NEGF_OK;
+}
+
+// ---- small systems: the single-kernel path (k_small_fused.hip)
+bool small_path(const negf_ctx* c, const SigmaProvider* p)
+{
+    if (c->small_algo != 0 || c->inverse_algo != 0 || !small_fused_supported(c->n)) return false;
+    if (p->kind == SK_CONST || p->kind == SK_PRECOMPUTED) return true;
+    return (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) && !p->d_xi && p->d_pos;
+}
+
+// arguments of the fused kernel for the energies [m0, m0 + nb) of provider p (Sigma blocks of a block provider are in
+// c->d_blk: run_sigma_blocks has run for exactly this range)
+SmallFusedArgs small_args(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cplx* E)
+{
+    SmallFusedArgs a;
+    a.n = c->n; a.m = nb; a.E = E + m0; a.S = c->d_S; a.H = c->d_F;
+    a.info = c->d_info + m0;
+    const size_t n2 = (size_t)c->n * c->n;
+    if (p->kind == SK_CONST) a.H = p->d_hbase;
+    else if (p->kind == SK_PRECOMPUTED) { a.sig_dense = p->d_pre_tot + n2 * m0; a.sig_stride = n2; }
+    else { a.blk = c->d_blk; a.blk_stride = p->blk_stride; a.n_contacts = p->n_contacts; a.pos = p->d_pos; a.nc = p->d_nc; a.blk_off = p->d_blk_off; }
+    return a;
 }
 
 int ensure_mbuffers(negf_ctx* c, int m, int contacts)
@@ -275,7 +377,7 @@ int run_inverse(negf_ctx* c, int nb, int* info)
     bool in_b = false;
     if (algo == 2) {
         // false: no blocked kernel serves this n (nothing was launched) -> the unblocked kernel
-        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info);
+        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info, &c->gj_side);
         if (!in_b) algo = 1;
     }
     if (algo == 1 && !launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info)) return NEGF_EINVAL;
@@ -423,6 +525,29 @@ int run_assemble(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cplx* E)
         return NEGF_EINVAL;
     }
     return NEGF_OK;
+}
+
+// G(E) for the batch [m0, m0 + nb): assemble + inverse, leaving c->G / c->W1 / c->W2 set.  Small systems take the
+// fused kernel in STORE mode (one launch, the matrix stays on the CU; k_small_fused.hip).
+int run_assemble_inverse(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cplx* E)
+{
+    int rc;
+    if (small_path(c, p)) {
+        if (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) {
+            if ((rc = run_sigma_blocks(c, p, nb, E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
+                                       c->d_conv + (size_t)m0 * p->n_contacts))) return rc;
+        }
+        ProfScope ps(c, "small");
+        SmallFusedArgs a = small_args(c, p, m0, nb, E);
+        a.Gout = c->d_A; a.g_stride = (size_t)c->n * c->n;
+        launch_small_fused(c->stream, a);
+        negf_count_flops(8.0 * c->n * (double)c->n * c->n * nb, 0.0);
+        NEGF_HIP_CHECK(hipGetLastError());
+        c->G = c->d_A; c->W1 = c->d_T1; c->W2 = c->d_T2;
+        return NEGF_OK;
+    }
+    if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
+    return run_inverse(c, nb, c->d_info + m0);
 }
 
 // dense Gamma_b = i (Sigma_c - Sigma_c^H) for batch [m0, m0+nb) into `out`
@@ -595,9 +720,15 @@ void negf_destroy(negf_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (auto* p : c->providers) free_provider(p);
     free_workspace(c); free_mbuffers(c); free_gcache(c);
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_cap = 0; }
+    if (c->gj_side.ok) {
+        (void)hipEventDestroy(c->gj_side.fork);
+        for (int g = 0; g < GjSideStreams::MAXG - 1; ++g) { (void)hipStreamDestroy(c->gj_side.s[g]); (void)hipEventDestroy(c->gj_side.join[g]); }
+        c->gj_side.ok = false;
+    }
     for (auto& sl : c->sys) { dev_free(sl.dF); dev_free(sl.dS); }
     c->d_F = c->d_S = nullptr;
-    dev_free(c->d_acc);
+    dev_free(c->d_acc); dev_free(c->d_seg_out);
     prof_resolve(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -622,6 +753,13 @@ int negf_set_inverse_algo(negf_ctx* c, int algo)
 {
     if (!c || algo < 0 || algo > 2) return NEGF_EINVAL;
     c->inverse_algo = algo;
+    return NEGF_OK;
+}
+
+int negf_set_small_algo(negf_ctx* c, int algo)
+{
+    if (!c || algo < 0 || algo > 1) return NEGF_EINVAL;
+    c->small_algo = algo;
     return NEGF_OK;
 }
 
@@ -775,6 +913,19 @@ static int setup_blocks(negf_ctx* c, SigmaProvider* p, int n_contacts, const int
         (rc = upload(c, p->d_blk_off, p->blk_off.data(), (size_t)n_contacts)) ||
         (rc = upload(c, p->d_inds_off, p->inds_off.data(), (size_t)n_contacts)))
         return rc;
+    // position of every orbital in each contact's index list (the small fused kernel subtracts the contact blocks while
+    // it assembles); a list that names an orbital twice has no such map and keeps the scatter kernels
+    std::vector<int> pos((size_t)n_contacts * c->n, -1);
+    bool unique = true;
+    for (int k = 0; k < n_contacts; ++k)
+        for (int a = 0; a < nc[k]; ++a) {
+            int& slot = pos[(size_t)k * c->n + p->h_inds[p->inds_off[k] + a]];
+            if (slot >= 0) unique = false;
+            slot = a;
+        }
+    if (unique) {
+        if ((rc = dev_alloc(&p->d_pos, pos.size())) || (rc = upload(c, p->d_pos, pos.data(), pos.size()))) return rc;
+    }
     return NEGF_OK;
 }
 
@@ -800,12 +951,13 @@ int negf_sigma_chain1d(negf_ctx* c, int n_contacts, const int* nc, const int* in
             (rc = upload(c, *dsts[k], reinterpret_cast<const cplx*>(srcs[k]), tot))) { free_provider(p); return rc; }
     }
     // what g(E) depends on, for the context's g(E) cache
-    p->h_lead.reserve(4 * tot);
+    p->h_lead = std::make_shared<std::vector<cplx>>();
+    p->h_lead->reserve(4 * tot);
     for (int k = 0; k < 4; ++k) {
         const cplx* src = reinterpret_cast<const cplx*>(srcs[k]);
-        p->h_lead.insert(p->h_lead.end(), src, src + tot);
+        p->h_lead->insert(p->h_lead->end(), src, src + tot);
     }
-    p->lead_hash = hash_words(p->h_lead.data(), p->h_lead.size() * sizeof(cplx));
+    p->lead_hash = hash_words(p->h_lead->data(), p->h_lead->size() * sizeof(cplx));
     p->eta = eta; p->conv = conv; p->relFactor = relFactor; p->max_iter = max_iter;
     p->force_iters = force_iters;
     *handle = add_provider(c, p);
@@ -909,6 +1061,40 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
     NEGF_HIP_CHECK(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
     if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
+    if (small_path(c, p) && m > 0) {
+        // n <= 96: assemble + inverse + weighted sum in one kernel (plus the reduction of the workgroups' partial sums);
+        // no n x n work area in HBM at all.  Grids above SMALL_CHUNK points go through in chunks (the Sigma blocks of a
+        // block provider are staged per chunk); chunk sums are added in order.
+        const cplx* E = reinterpret_cast<const cplx*>(E_dev);
+        const cplx* w = reinterpret_cast<const cplx*>(w_dev);
+        cplx* out = reinterpret_cast<cplx*>(out_dev);
+        constexpr int SMALL_CHUNK = 16384;
+        const bool blocks = p->kind == SK_CHAIN1D || p->kind == SK_BETHE;
+        const int chunk = std::min(m, SMALL_CHUNK);
+        if (blocks && (rc = ensure_blk(c, (size_t)chunk * p->blk_stride))) return rc;
+        const size_t part_need = (size_t)small_fused_grid(c->n, chunk) * n2 + (m > chunk ? n2 : 0);
+        if (part_need > c->small_part_cap) {
+            NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+            dev_free(c->d_small_part); c->small_part_cap = 0;
+            if ((rc = dev_alloc(&c->d_small_part, part_need))) return rc;
+            c->small_part_cap = part_need;
+        }
+        cplx* chunk_sum = c->d_small_part + (size_t)small_fused_grid(c->n, chunk) * n2;   // (only with several chunks)
+        for (int m0 = 0; m0 < m; m0 += chunk) {
+            const int nb = std::min(chunk, m - m0);
+            if (blocks && (rc = run_sigma_blocks(c, p, nb, E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
+                                                 c->d_conv + (size_t)m0 * p->n_contacts))) return rc;
+            ProfScope ps(c, "small");
+            SmallFusedArgs a = small_args(c, p, m0, nb, E);
+            a.w = w + m0; a.partial = c->d_small_part; a.out = m0 == 0 ? out : chunk_sum;
+            launch_small_fused(c->stream, a);
+            if (m0 > 0) launch_cadd(c->stream, n2, out, chunk_sum, out);
+            negf_count_flops(8.0 * c->n * (double)c->n * c->n * nb, 0.0);
+        }
+        c->last_m = m;
+        NEGF_HIP_CHECK(hipGetLastError());
+        return NEGF_OK;
+    }
     if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
     const cplx* E = reinterpret_cast<const cplx*>(E_dev);
     const cplx* w = reinterpret_cast<const cplx*>(w_dev);
@@ -916,8 +1102,7 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
     NEGF_HIP_CHECK(hipMemsetAsync(out, 0, n2 * sizeof(cplx), c->stream));
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
-        if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
-        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
+        if ((rc = run_assemble_inverse(c, p, m0, nb, E))) return rc;
         ProfScope ps(c, "accumulate");
         launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out, c->W2);
     }
@@ -946,8 +1131,7 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
     NEGF_HIP_CHECK(hipMemsetAsync(out, 0, n2 * sizeof(cplx), c->stream));
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
-        if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
-        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
+        if ((rc = run_assemble_inverse(c, p, m0, nb, E))) return rc;
         if (compact_available(c, p)) {
             // G Gamma G^H = (G[:, I] Gamma_II) G[:, I]^H : Gc and X live in the free buffer W2
             GammaSmall g;
@@ -1010,8 +1194,7 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
     const int half = std::max(1, c->batch / 2);
     for (int m0 = 0; m0 < m; m0 += half) {
         const int nb = std::min(half, m - m0);
-        if ((rc = run_assemble(c, p, m0, nb, E))) return rc;
-        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
+        if ((rc = run_assemble_inverse(c, p, m0, nb, E))) return rc;
         if (spin_mode == NEGF_SPIN_RESTRICTED && compact_available(c, p)) {
             // T = Re sum_ij Y_ij conj(G_ij), Y = Gamma_L G Gamma_R: only G[I_L, I_R] enters
             GammaSmall gL, gR;
@@ -1118,19 +1301,47 @@ int negf_last_iters(negf_ctx* c, int handle, int m, int* iters, int* converged)
 }
 
 // --------------------------------------------------------------- host variants
+// The host-pointer entry points stage through ONE pinned buffer of the context: [E | w] go up with two asynchronous
+// copies and no synchronisation (the buffer is ours; the call's final synchronisation covers them), the result and the
+// per-energy info come down into [out | info] and are handed over after ONE synchronisation.  (Pageable copies with a
+// synchronisation each made a 2-point integral of a 60-orbital system cost 0.5 ms of host time: bench.py --config scf.)
 static int stage_grid(negf_ctx* c, int m, int contacts, const double* E, const double* w)
 {
     int rc = ensure_mbuffers(c, m, contacts);
     if (rc) return rc;
-    if (E) {
+    const size_t gb = (size_t)m * sizeof(cplx);
+    const size_t n2b = (size_t)c->n * c->n * sizeof(cplx);
+    if ((rc = ensure_pinned(c, 2 * gb + n2b + (size_t)m * sizeof(int) + 64))) return rc;
+    if (E && m > 0) {
         c->h_E_valid = false;
-        if ((rc = upload(c, c->d_E, reinterpret_cast<const cplx*>(E), (size_t)m))) return rc;
+        std::memcpy(c->h_pin, E, gb);
+        NEGF_HIP_CHECK(hipMemcpyAsync(c->d_E, c->h_pin, gb, hipMemcpyHostToDevice, c->stream));
         const cplx* Eh = reinterpret_cast<const cplx*>(E);
         c->h_E.assign(Eh, Eh + m);
         c->h_E_valid = true;
     }
-    if (w && (rc = upload(c, c->d_w, reinterpret_cast<const cplx*>(w), (size_t)m))) return rc;
+    if (w && m > 0) {
+        std::memcpy(c->h_pin + gb, w, gb);
+        NEGF_HIP_CHECK(hipMemcpyAsync(c->d_w, c->h_pin + gb, gb, hipMemcpyHostToDevice, c->stream));
+    }
     return NEGF_OK;
+}
+
+// result (n x n, from d_src) and per-energy info back to the caller: two asynchronous copies into the pinned buffer,
+// one synchronisation; returns NEGF_ESINGULAR when an energy reported a zero pivot
+static int fetch_matrix_and_info(negf_ctx* c, int m, const cplx* d_src, double* out_host, int* info_host)
+{
+    const size_t gb = (size_t)m * sizeof(cplx);
+    const size_t n2b = (size_t)c->n * c->n * sizeof(cplx);
+    unsigned char* pout = c->h_pin + 2 * gb;
+    int* pinfo = reinterpret_cast<int*>(pout + n2b);
+    NEGF_HIP_CHECK(hipMemcpyAsync(pout, d_src, n2b, hipMemcpyDeviceToHost, c->stream));
+    if (m > 0) NEGF_HIP_CHECK(hipMemcpyAsync(pinfo, c->d_info, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    { const int wrc = wait_stream(c); if (wrc) return wrc; }
+    std::memcpy(out_host, pout, n2b);
+    int rc = NEGF_OK;
+    for (int i = 0; i < m; ++i) { if (info_host) info_host[i] = pinfo[i]; if (pinfo[i] != 0) rc = NEGF_ESINGULAR; }
+    return rc;
 }
 
 int negf_gr_int(negf_ctx* c, int handle, int m, const double* E, const double* w, double* out,
@@ -1144,8 +1355,76 @@ int negf_gr_int(negf_ctx* c, int handle, int m, const double* E, const double* w
     if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
     if ((rc = negf_gr_int_dev(c, handle, m, reinterpret_cast<double*>(c->d_E),
                               reinterpret_cast<double*>(c->d_w), reinterpret_cast<double*>(c->d_acc)))) return rc;
-    if ((rc = download(c, reinterpret_cast<cplx*>(out), c->d_acc, (size_t)c->n * c->n))) return rc;
-    return reduce_info(c, m, info);
+    return fetch_matrix_and_info(c, m, c->d_acc, out, info);
+}
+
+// Several integrals of the same system in ONE pass: the energies are nseg consecutive segments (seg_end[s] = index one
+// past the last point of segment s) and out receives one n x n sum per segment.  This is how the adaptive integrations
+// (nested ANT levels 2, 6, 18, 54 ... of density.py:211-273; the doubling real-axis grids of :438-484) are served: the
+// levels a refinement is going to visit are evaluated together -- a level of 2 ... 36 points alone in a launch is pure
+// latency on this chip -- and handed back level by level.
+int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const double* w, int nseg,
+                    const int* seg_end, double* out, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out || nseg <= 0 || !seg_end || (m > 0 && (!E || !w))) return NEGF_EINVAL;
+    for (int sg = 0, prev = 0; sg < nseg; ++sg) { if (seg_end[sg] < prev || seg_end[sg] > m) return NEGF_EINVAL; prev = seg_end[sg]; }
+    if (seg_end[nseg - 1] != m) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
+    // results: [nseg][n*n] on the device, then one download
+    if ((size_t)nseg * n2 > c->seg_out_cap) {
+        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+        dev_free(c->d_seg_out); c->seg_out_cap = 0;
+        if ((rc = dev_alloc(&c->d_seg_out, (size_t)nseg * n2))) return rc;
+        c->seg_out_cap = (size_t)nseg * n2;
+    }
+    if ((rc = ensure_pinned(c, 2 * (size_t)m * sizeof(cplx) + nseg * n2 * sizeof(cplx) + (size_t)m * sizeof(int) + 64))) return rc;
+    const cplx* Ed = c->d_E; const cplx* wd = c->d_w;
+    if (m > 0 && small_path(c, p) && m <= 4096) {
+        const bool blocks = p->kind == SK_CHAIN1D || p->kind == SK_BETHE;
+        if (blocks && (rc = ensure_blk(c, (size_t)m * p->blk_stride))) return rc;
+        if ((size_t)m * n2 > c->small_part_cap) {
+            NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+            dev_free(c->d_small_part); c->small_part_cap = 0;
+            if ((rc = dev_alloc(&c->d_small_part, (size_t)m * n2))) return rc;
+            c->small_part_cap = (size_t)m * n2;
+        }
+        if (blocks && (rc = run_sigma_blocks(c, p, m, Ed, c->d_iters, c->d_conv))) return rc;
+        ProfScope ps(c, "small");
+        SmallFusedArgs a = small_args(c, p, 0, m, Ed);
+        a.w = wd; a.partial = c->d_small_part; a.out = c->d_seg_out; a.nseg = nseg; a.seg_end = seg_end;
+        launch_small_fused(c->stream, a);
+        negf_count_flops(8.0 * c->n * (double)c->n * c->n * m, 0.0);
+    } else {
+        if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
+        NEGF_HIP_CHECK(hipMemsetAsync(c->d_seg_out, 0, (size_t)nseg * n2 * sizeof(cplx), c->stream));
+        for (int m0 = 0; m0 < m; m0 += c->batch) {
+            const int nb = std::min(c->batch, m - m0);
+            if ((rc = run_assemble_inverse(c, p, m0, nb, Ed))) return rc;
+            ProfScope ps(c, "accumulate");
+            for (int sg = 0, start = 0; sg < nseg; start = seg_end[sg], ++sg) {
+                const int lo = std::max(start, m0), hi = std::min(seg_end[sg], m0 + nb);
+                if (hi > lo)
+                    launch_accumulate(c->stream, (int)n2, hi - lo, wd + lo, c->G + (size_t)(lo - m0) * n2, c->d_seg_out + (size_t)sg * n2, c->W2);
+            }
+        }
+    }
+    c->last_m = m;
+    NEGF_HIP_CHECK(hipGetLastError());
+    // one download of all segment sums and the info, one synchronisation
+    unsigned char* pout = c->h_pin + 2 * (size_t)m * sizeof(cplx);
+    int* pinfo = reinterpret_cast<int*>(pout + nseg * n2 * sizeof(cplx));
+    NEGF_HIP_CHECK(hipMemcpyAsync(pout, c->d_seg_out, nseg * n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    if (m > 0) NEGF_HIP_CHECK(hipMemcpyAsync(pinfo, c->d_info, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    std::memcpy(out, pout, nseg * n2 * sizeof(cplx));
+    rc = NEGF_OK;
+    for (int i = 0; i < m; ++i) { if (info) info[i] = pinfo[i]; if (pinfo[i] != 0) rc = NEGF_ESINGULAR; }
+    return rc;
 }
 
 int negf_gless_int(negf_ctx* c, int handle, int ind, int m, const double* E, const double* w,
@@ -1159,8 +1438,7 @@ int negf_gless_int(negf_ctx* c, int handle, int ind, int m, const double* E, con
     if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
     if ((rc = negf_gless_int_dev(c, handle, ind, m, reinterpret_cast<double*>(c->d_E),
                                  reinterpret_cast<double*>(c->d_w), reinterpret_cast<double*>(c->d_acc)))) return rc;
-    if ((rc = download(c, reinterpret_cast<cplx*>(out), c->d_acc, (size_t)c->n * c->n))) return rc;
-    return reduce_info(c, m, info);
+    return fetch_matrix_and_info(c, m, c->d_acc, out, info);
 }
 
 int negf_gr_batch(negf_ctx* c, int handle, int m, const double* E, double* G_out, int* info)
@@ -1175,8 +1453,7 @@ int negf_gr_batch(negf_ctx* c, int handle, int m, const double* E, double* G_out
     if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
-        if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
-        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
+        if ((rc = run_assemble_inverse(c, p, m0, nb, c->d_E))) return rc;
         if ((rc = download(c, reinterpret_cast<cplx*>(G_out) + n2 * m0, c->G, n2 * nb))) return rc;
     }
     c->last_m = m;
@@ -1221,8 +1498,7 @@ int negf_dos(negf_ctx* c, int handle, int m, const double* E, double* dos_total,
     if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
-        if ((rc = run_assemble(c, p, m0, nb, c->d_E))) return rc;
-        if ((rc = run_inverse(c, nb, c->d_info + m0))) return rc;
+        if ((rc = run_assemble_inverse(c, p, m0, nb, c->d_E))) return rc;
         { ProfScope ps(c, "trace"); launch_dos(c->stream, c->n, nb, c->G, c->d_scal + m0, dos_site ? c->d_site : nullptr); }
         if (dos_site && (rc = download(c, dos_site + (size_t)m0 * c->n, c->d_site, (size_t)nb * c->n))) return rc;
     }
@@ -1332,6 +1608,13 @@ int negf_set_chain_cache(negf_ctx* c, int max_grids)
     if (max_grids < (int)c->gcache.size()) free_gcache(c);     // shrinking (or switching off) drops every entry
     c->gcache_max = max_grids;
     c->gcache.reserve((size_t)max_grids);                      // entries are handed out by pointer: no reallocation later
+    return NEGF_OK;
+}
+
+int negf_set_chain_cache_bytes(negf_ctx* c, long long max_bytes)
+{
+    if (!c || max_bytes < 0) return NEGF_EINVAL;
+    c->gcache_bytes_max = (size_t)max_bytes;
     return NEGF_OK;
 }
 

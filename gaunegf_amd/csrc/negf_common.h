@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 #include "../../include/negf.h"
 
 // ------------------------------------------------------------------ complex
@@ -79,6 +80,7 @@ struct SigmaProvider {
     int* d_inds = nullptr;         // concatenated orbital indices
     int *d_nc = nullptr, *d_blk_off = nullptr, *d_inds_off = nullptr;   // device copies
     int *d_n_atoms = nullptr, *d_atom_off = nullptr;
+    int* d_pos = nullptr;          // [n_contacts][n]: position of orbital i in contact c's index list, -1 outside (small fused path)
     std::vector<int> inds_off;     // offset of contact c in d_inds
     std::vector<int> h_inds;
     // CHAIN1D matrices, concatenated [sum nc^2] each
@@ -86,7 +88,7 @@ struct SigmaProvider {
          *d_tau = nullptr, *d_Stau = nullptr;
     // host copy of alpha | Salpha | beta | Sbeta and its 64-bit hash: what the surface Green's function depends on
     // besides eta / conv / relFactor / max_iter -- the key of the context's g(E) cache (ChainGEntry)
-    std::vector<cplx> h_lead;
+    std::shared_ptr<std::vector<cplx>> h_lead;     // shared with the cache entries this provider fills
     unsigned long long lead_hash = 0;
     double eta = 0, conv = 0, relFactor = 0, mix = 0;
     int max_iter = 0, force_iters = -1;
@@ -128,7 +130,7 @@ struct SigmaProvider {
 // level all find it.  A hit runs only Sigma = t g t^H (the last pass of the chain kernel) and is bit-identical to a miss.
 struct ChainGEntry {
     std::vector<int> nc;
-    std::vector<cplx> lead;
+    std::shared_ptr<std::vector<cplx>> lead;
     unsigned long long lead_hash = 0, E_hash = 0;
     double eta = 0, conv = 0, relFactor = 0;
     int max_iter = 0, force_iters = -1;
@@ -137,6 +139,15 @@ struct ChainGEntry {
     int* d_it = nullptr;    int* d_cv = nullptr;   size_t it_cap = 0;   // [energies][n_contacts]
     unsigned long long used = 0;
     bool valid = false;
+};
+
+// side streams of the windowed inverse (small batches are cut into up to four stream groups, k_inverse_blocked.hip):
+// owned by the context
+struct GjSideStreams {
+    static constexpr int MAXG = 4;
+    hipStream_t s[MAXG - 1] = {};
+    hipEvent_t fork = nullptr, join[MAXG - 1] = {};
+    bool ok = false;
 };
 
 struct ProfEntry { double ms = 0; int launches = 0; double flops_alg = 0, flops_mfma = 0; };
@@ -191,8 +202,9 @@ struct negf_ctx {
     bool h_E_valid = false;        //   keys on the energies without a device round trip
     // g(E) cache of the 1-D chain providers (negf_set_chain_cache)
     std::vector<ChainGEntry> gcache;
-    int gcache_max = 8;            // entries (evaluated grids) kept, 0 = off
+    int gcache_max = 512;          // entries (evaluated grids) kept, 0 = off
     size_t gcache_entry_bytes_max = (size_t)4 << 30;
+    size_t gcache_bytes_max = (size_t)8 << 30;     // all entries together
     unsigned long long gcache_clock = 0, gcache_hits = 0, gcache_misses = 0;
     cplx* d_acc = nullptr;         // [n*n] result staging
     double* d_scal = nullptr;      // [m_cap][8] scalar outputs
@@ -201,6 +213,15 @@ struct negf_ctx {
     int gamma_algo = 0;            // 0: compact Gamma products when the provider allows, 1: always dense
     cplx* d_gsmall = nullptr;      // small Gamma matrices of a batch (compact path)
     size_t gsmall_cap = 0;
+    cplx* d_seg_out = nullptr;     // [segments][n*n] results of negf_gr_int_seg
+    size_t seg_out_cap = 0;
+    cplx* d_small_part = nullptr;  // per-workgroup partial sums of the small fused kernel
+    size_t small_part_cap = 0;
+    GjSideStreams gj_side;
+    int small_algo = 0;            // 0: n <= 96 takes the fused single-kernel path, 1: never (negf_set_small_algo)
+    // pinned host staging of the host-pointer entry points: [E | w] up, [result | info] down, ONE synchronisation
+    unsigned char* h_pin = nullptr;
+    size_t h_pin_cap = 0;
     int last_m = 0;
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -237,7 +258,8 @@ void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S
 bool launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
 // out-of-place ping-pong between A and B (both [nb][stride]); returns true when the
 // inverses end up in B, false when in A
-bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info);
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info,
+                            GjSideStreams* side = nullptr);
 bool inverse_blocked_supported(int n);
 
 // acc += sum_b w[b] * X[b]   (fixed summation order, deterministic); `part` is scratch of
@@ -304,3 +326,29 @@ void launch_bethe_raw(hipStream_t st, const double* d_H, const double* d_S, cons
                       const cplx* E, cplx* out, int* iters, int* converged);
 
 int run_mfma_selftest(hipStream_t st, double* max_err);
+
+// Small systems (n <= 96): assemble + invert (+ accumulate) in one kernel, k_small_fused.hip
+struct SmallFusedArgs {
+    int n = 0, m = 0, gp = 0;
+    const cplx* E = nullptr;          // [m]
+    const cplx* w = nullptr;          // [m]   (accumulate mode)
+    const cplx* S = nullptr;          // [n*n]
+    const cplx* H = nullptr;          // [n*n]  F, or F + Sigma_tot of a constant provider
+    const cplx* sig_dense = nullptr;  // [m][sig_stride] dense Sigma per energy, or null
+    size_t sig_stride = 0;
+    const cplx* blk = nullptr;        // [m][blk_stride] contact blocks of Sigma(E), or null (then n_contacts = 0)
+    int blk_stride = 0, n_contacts = 0;
+    const int* pos = nullptr;         // [n_contacts][n] position of an orbital in the contact's index list, -1 outside
+    const int* nc = nullptr;          // [n_contacts]
+    const int* blk_off = nullptr;     // [n_contacts]
+    cplx* partial = nullptr;          // [small_fused_grid(n, m)][n*n] scratch (accumulate mode)
+    cplx* out = nullptr;              // [n*n] sum_m w_m G(E_m)   (accumulate mode)
+    cplx* Gout = nullptr;             // non-null: STORE mode, G(E_m) -> Gout + m * g_stride
+    size_t g_stride = 0;
+    int* info = nullptr;              // [m]
+    int nseg = 0;                     // > 0: the energies are nseg consecutive segments ending at seg_end[s] (HOST array);
+    const int* seg_end = nullptr;     //      out holds one n x n sum per segment
+};
+bool small_fused_supported(int n);
+int small_fused_grid(int n, int m);
+void launch_small_fused(hipStream_t st, SmallFusedArgs a);

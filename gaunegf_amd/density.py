@@ -18,7 +18,10 @@ import numpy as np
 from scipy.special import roots_legendre
 
 from .config import (TEMPERATURE, ADAPTIVE_INTEGRATION_TOL, N_KT, MAX_CYCLES, MAX_GRID_POINTS)
-from .integrate import GrInt, GrLessInt
+from .integrate import GrInt, GrLessInt, GrIntSegments
+
+_ENGINE_GRINT = GrInt     # speculation over several levels only while GrInt is the engine's own: a rebound name
+                          # (the bookkeeping spies, an oracle-served replay) sees the reference's call sequence
 
 har_to_eV = 27.211386   # eV/Hartree
 kB = 8.617e-5           # eV/Kelvin
@@ -46,26 +49,95 @@ def getANTPoints(N):
     return np.concatenate((x, -1 * x)), np.concatenate((w, w))
 
 
-def integratePointsAdaptiveANT(computePoint, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, debug=False):
-    """Adaptive nested quadrature (density.py:211-273): levels N = 2, 6, 18, ...; each
-    level sends ONLY its new nodes to ``computePoint(x, w)`` and rescales the running
-    value by the nested-weight ratio; stops when max|dP| < tol or N would exceed maxN."""
-    prev_x = prev_sumW = P = new_P = None
+SPECULATIVE_POINTS = 64      # new nodes evaluated per launch AHEAD of the convergence test (0: level by level);
+SPECULATIVE_POINTS_ONE_CU = 192  # ... for systems whose inverse is ONE workgroup per matrix (n <= 256): up to one matrix
+                                 # per compute unit a launch takes what a single matrix does (n = 200: 2 points 0.61 ms,
+                                 # 108 points 0.68 ms, 324 points 1.44 ms) -- levels 2 ... 162 in one go
+SPECULATIVE_POINTS_SMALL = 512   # ... and for n <= 96 (matrix in registers, several per compute unit; n = 60: 2 points
+                                 # 93 us, 324 points 132 us): every level of the rule, 486 points, in one go
+
+
+def _speculation_budget(F):
+    """How many new nodes an adaptive integration may evaluate ahead of its convergence test, for this system."""
+    if SPECULATIVE_POINTS <= 0:
+        return 0
+    n = np.shape(F)[0]
+    return SPECULATIVE_POINTS_SMALL if n <= 96 else SPECULATIVE_POINTS_ONE_CU if n <= 256 else SPECULATIVE_POINTS
+
+
+_ANT_LEVELS = {}
+
+
+def _ant_levels(maxN):
+    """The levels N = 2, 6, 18, ... <= maxN of the nested rule as (N, new nodes, their weights, nested-weight ratio):
+    the node bookkeeping of density.py:239-252 (old nodes recognised by value, rounded to 14 digits).  Depends on maxN
+    only: built once per value (an SCF step runs ~50 adaptive integrations)."""
+    if maxN in _ANT_LEVELS:
+        return _ANT_LEVELS[maxN]
+    out = []
+    prev_x = prev_sumW = None
     N = 2
-    maxDP = 1e10
     while N <= maxN:
         x, w = getANTPoints(N)
         if prev_x is None:
-            P = computePoint(x[0:2], w[0:2])
+            out.append((N, x[0:2], w[0:2], None))
         else:
             old_mask = np.isin(np.round(x, 14), np.round(prev_x, 14))
             assert int(old_mask.sum()) == prev_x.size, "Old nodes mismatch"
             ratio = float(np.sum(w[old_mask]) / prev_sumW)
             new_mask = ~old_mask
+            out.append((N, x[new_mask], w[new_mask], ratio))
+        prev_x = x
+        prev_sumW = float(np.sum(w))
+        N *= 3
+    for _, xs, ws, _ in out:
+        xs.setflags(write=False); ws.setflags(write=False)
+    _ANT_LEVELS[maxN] = out
+    return out
+
+
+def integratePointsAdaptiveANT(computePoint, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, debug=False,
+                               computeLevels=None, budget=None):
+    """Adaptive nested quadrature (density.py:211-273): levels N = 2, 6, 18, ...; each
+    level sends ONLY its new nodes to ``computePoint(x, w)`` and rescales the running
+    value by the nested-weight ratio; stops when max|dP| < tol or N would exceed maxN.
+
+    ``computeLevels([(x, w), ...]) -> [value, ...]`` (optional) evaluates the new nodes of SEVERAL levels in one go:
+    the levels the refinement is about to visit are then requested together while they add up to at most
+    ``budget`` nodes (default SPECULATIVE_POINTS: 2 + 4 + 12 + 36) -- on a GPU a launch of 2 ... 36 energy points costs
+    what a launch of 54 does -- and consumed level by level with the reference's own update and stopping test; values
+    computed past the level that converges are dropped."""
+    levels = _ant_levels(maxN)
+    ahead = {}                                          # level index -> value, evaluated ahead of its turn
+    if budget is None:
+        budget = SPECULATIVE_POINTS
+
+    def value_of(i):
+        if i not in ahead:
+            group, pts = [], 0
+            for j in range(i, len(levels)):
+                if group and (computeLevels is None or debug or pts + levels[j][1].size > budget):
+                    break
+                group.append(j); pts += levels[j][1].size
+            if len(group) == 1:
+                ahead[i] = computePoint(levels[i][1], levels[i][2])
+            else:
+                for j, v in zip(group, computeLevels([(levels[j][1], levels[j][2]) for j in group])):
+                    ahead[j] = v
+        return ahead.pop(i)
+
+    P = new_P = None
+    N = 2
+    maxDP = 1e10
+    for i, (N, x_new, w_new, ratio) in enumerate(levels):
+        if ratio is None:
+            P = value_of(i)
+        else:
             new_P = P * ratio
-            new_P += computePoint(x[new_mask], w[new_mask])
+            new_P += value_of(i)
             maxDP = np.max(np.abs(new_P - P))
             if debug:
+                x, w = getANTPoints(N)
                 direct = computePoint(x, w)
                 print(f"N={N}, nested-weight ratio ~ {ratio:.3f}, maxDP={maxDP:.3e}")
                 print(f"Direct Calculation: N={N}, maxDP={np.max(np.abs(direct - P)):.3e}, "
@@ -74,11 +146,7 @@ def integratePointsAdaptiveANT(computePoint, tol=ADAPTIVE_INTEGRATION_TOL, maxN=
             if maxDP < tol:
                 print(f'Adaptive integration converged to {maxDP:.3e} in {N} points.')
                 return new_P
-        prev_x = x
-        prev_sumW = float(np.sum(w))
-        N *= 3
-    N /= 3
-    print(f'Adaptive integration reached full grid ({N} points), final error {maxDP:.3e}')
+    print(f'Adaptive integration reached full grid ({N / 1} points), final error {maxDP:.3e}')
     return new_P
 
 
@@ -176,13 +244,28 @@ def densityRealN(F, S, g, Emin, mu, N=100, T=TEMPERATURE, showText=True):
 
 
 def densityReal(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATURE, maxN=MAX_CYCLES, debug=False):
-    """Doubling wrapper around densityRealN (density.py:438-484)."""
+    """Doubling wrapper around densityRealN (density.py:438-484): N = 1, 2, 4, ... Gauss-Legendre points until two
+    successive densities agree to tol.  The grids the doubling is about to visit are evaluated together while they add
+    up to at most SPECULATIVE_POINTS points (1 + 2 + ... + 32: one launch instead of six) and compared in the
+    reference's order; densities past the converged one are dropped."""
     P = np.zeros_like(F)
     N = 1
     maxDP = 1e9
+    ahead = {}
     while N < maxN:
         P_ = P.copy()
-        P = densityRealN(F, S, g, Emin, mu, N, T, showText=False)
+        if N not in ahead:
+            group, pts, M = [], 0, N
+            while M < maxN and (not group or pts + M <= _speculation_budget(F)):
+                group.append(M); pts += M; M *= 2
+            if len(group) == 1 or debug or GrInt is not _ENGINE_GRINT:
+                group = [N]
+                ahead[N] = densityRealN(F, S, g, Emin, mu, N, T, showText=False)
+            else:
+                sums = GrIntSegments(F, S, g, [real_axis_grid(Emin, mu, M, T) for M in group])
+                for M, v in zip(group, sums):
+                    ahead[M] = (-1 + 0j) * np.imag(v) / (np.pi)
+        P = ahead.pop(N)
         maxDP = np.max(np.abs(P - P_))
         if maxDP < tol:
             print(f'Adaptive integration converged to {maxDP:.3e} in {N} points.')
@@ -267,10 +350,18 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
         return half_width * (x) + mu, half_width * w
 
     def integral_over(node_map):
-        def level(x, w):
+        def grid(x, w):
             z, wz = node_map(x, w)
-            return GrInt(F, S, g, z, wz * fermi(z, mu, T))
-        return integratePointsAdaptiveANT(level, tol=tol, debug=debug)
+            return z, wz * fermi(z, mu, T)
+
+        def level(x, w):
+            return GrInt(F, S, g, *grid(x, w))
+
+        def levels(nodes):
+            return GrIntSegments(F, S, g, [grid(x, w) for x, w in nodes])
+        return integratePointsAdaptiveANT(level, tol=tol, debug=debug,
+                                          computeLevels=levels if GrInt is _ENGINE_GRINT else None,
+                                          budget=_speculation_budget(F))
 
     print('Complex Contour Integration:')
     total = integral_over(on_arc)
@@ -350,14 +441,41 @@ def _orbital_energies(F, S, hermitian=False):
 
 def calcEmin(F, S, g, tol=FERMI_CALCULATION_TOL, maxN=MAX_CYCLES):
     """Lower contour bound: walk down in 1 eV steps from (lowest orbital - 5 eV) until the
-    DOS falls below tol (density.py:821-836)."""
+    DOS falls below tol (density.py:821-836).
+
+    A provider that lives on the device serves the walk in batches: the energies the loop WOULD visit (the same repeated
+    ``Emin -= 1``, so the same floating-point values) are evaluated 8, 16, 32, ... at a time by one DOS launch each and
+    the first one at or below ``tol`` is taken -- same Emin, same sample count, without one provider upload, one
+    single-matrix launch and one download per step (a 200-orbital matrix alone in a launch costs 0.7 ms of latency)."""
     Emin = min(_orbital_energies(F, S)) - 5
     counter = 0
-    dP = _compute_dos_at_energy(Emin, F, S, g.sigmaTot(Emin))
-    while dP > tol and counter < maxN:
-        Emin -= 1
+    if hasattr(g, "_negf_lower"):
+        from .engine import get_engine
+        eng = get_engine()
+        eng.set_system(F, S)
+        handle = g._negf_lower(eng)
+        walk = [Emin]
+        dP, chunk, done = None, 8, False
+        while not done:
+            while len(walk) < min(counter + chunk, maxN + 1):
+                walk.append(walk[-1] - 1)
+            vals = eng.dos(handle, np.array(walk[counter:counter + chunk]), per_site=False)
+            for v in vals:
+                dP = float(v)
+                if not (dP > tol and counter < maxN):
+                    done = True
+                    break
+                counter += 1
+            else:
+                done = counter >= len(walk) and len(walk) > maxN
+            chunk *= 2
+        Emin = walk[min(counter, len(walk) - 1)]
+    else:
         dP = _compute_dos_at_energy(Emin, F, S, g.sigmaTot(Emin))
-        counter += 1
+        while dP > tol and counter < maxN:
+            Emin -= 1
+            dP = _compute_dos_at_energy(Emin, F, S, g.sigmaTot(Emin))
+            counter += 1
     if counter == maxN:
         print(f'Warning: Emin still not within tolerance (final value = {dP}) after {maxN} energy samples')
     print(f'Calculated Emin: {Emin} eV, DOS = {dP:.2E}')

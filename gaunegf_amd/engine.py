@@ -93,6 +93,10 @@ class Engine:
     def set_inverse_algo(self, algo):
         check(self._lib.negf_set_inverse_algo(self._ctx, int(algo)), "negf_set_inverse_algo")
 
+    def set_small_algo(self, algo):
+        """0: systems of n <= 96 take the single-kernel path (default), 1: the kernel sequence of larger systems."""
+        check(self._lib.negf_set_small_algo(self._ctx, int(algo)), "negf_set_small_algo")
+
     def set_gamma_algo(self, algo):
         """0: compact Gamma products where the provider allows (default), 1: dense n x n products."""
         check(self._lib.negf_set_gamma_algo(self._ctx, int(algo)), "negf_set_gamma_algo")
@@ -100,9 +104,15 @@ class Engine:
     def sync(self):
         check(self._lib.negf_sync(self._ctx), "negf_sync")
 
-    def set_chain_cache(self, max_grids):
-        """g(E) cache of the 1-D chain providers: number of evaluated grids kept in HBM (default 8, 0 = off)."""
-        check(self._lib.negf_set_chain_cache(self._ctx, int(max_grids)), "negf_set_chain_cache")
+    CHAIN_CACHE_DEFAULT = 512
+
+    def set_chain_cache(self, max_grids=None, max_bytes=None):
+        """g(E) cache of the 1-D chain providers: number of evaluated grids kept in HBM (default 512, 0 = off) and
+        their total size in bytes (default 8 GB)."""
+        if max_grids is not None:
+            check(self._lib.negf_set_chain_cache(self._ctx, int(max_grids)), "negf_set_chain_cache")
+        if max_bytes is not None:
+            check(self._lib.negf_set_chain_cache_bytes(self._ctx, int(max_bytes)), "negf_set_chain_cache_bytes")
 
     def chain_cache_clear(self):
         check(self._lib.negf_chain_cache_clear(self._ctx), "negf_chain_cache_clear")
@@ -252,6 +262,18 @@ class Engine:
                    "negf_gr_int")
         self._numerical(rc, info[:E.size], "gr_int")
         return out
+
+    def gr_int_seg(self, handle, segments):
+        """[sum_m w_m G(E_m) for (E, w) in segments] from ONE pass over all the energies (negf_gr_int_seg)."""
+        Es = [np.asarray(E).ravel() for E, _ in segments]
+        E, w = self._grid(np.concatenate(Es) if Es else np.zeros(0), np.concatenate([np.asarray(w).ravel() for _, w in segments]) if Es else np.zeros(0))
+        ends = np.ascontiguousarray(np.cumsum([e.size for e in Es]), dtype=np.int32)
+        out = np.zeros((len(segments), self.n, self.n), dtype=np.complex128)
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_gr_int_seg(self._ctx, handle, E.size, _ptr(E), _ptr(w), len(segments), _ptr(ends),
+                                             _ptr(out), _ptr(info)), "negf_gr_int_seg")
+        self._numerical(rc, info[:E.size], "gr_int_seg")
+        return [out[k] for k in range(len(segments))]
 
     def gless_int(self, handle, ind, E, w):
         E, w = self._grid(E, w)

@@ -189,6 +189,23 @@ def GrInt(F, S, g, Elist, weights):
     return _dist.sharded_sum(lambda idx: _partial_gr(engine, g, E[idx], w[idx]), E.size)
 
 
+def GrIntSegments(F, S, g, segments):
+    """``[GrInt(F, S, g, E, w) for (E, w) in segments]`` from ONE pass of the engine over all the energies
+    (negf_gr_int_seg) when ``g`` lives on the device; a plain loop of GrInt otherwise (foreign providers, spin-block
+    splitting, energy sharding across ranks).  The adaptive integrations of density.py hand the levels they are about
+    to visit over together: a level of 2 ... 36 points alone in a launch is latency, not work."""
+    F = np.asarray(F)
+    S = np.asarray(S)
+    segs = [(np.asarray(E), np.asarray(w)) for E, w in segments]
+    for E, w in segs:
+        _check(F, S, E, w)
+    if not hasattr(g, "_negf_lower") or _dist.is_active() or _split_depth or _spin_split(F, S, g) is not None or len(segs) < 2:
+        return [GrInt(F, S, g, E, w) for E, w in segs]
+    engine = get_engine()
+    engine.set_system(F, S)
+    return engine.gr_int_seg(g._negf_lower(engine), segs)
+
+
 def GrLessInt(F, S, g, Elist, weights, ind=None):
     """Integrated lesser Green's function, N x N complex (integrate.py:177-208).
     ``ind`` is None (total Sigma) or a contact index (0, -1, ...)."""

@@ -151,6 +151,15 @@ int negf_sigma_eval(negf_ctx* ctx, int handle, int contact, int m, const double*
 int negf_gr_int(negf_ctx* ctx, int handle, int m, const double* E_c128,
                 const double* w_c128, double* out_c128, int* info);
 
+/* Several GrInt integrals of one system in ONE pass: the m energies are nseg consecutive segments, seg_end[s] = index
+ * one past segment s (seg_end[nseg-1] = m), out [nseg][n][n] receives one sum per segment.  Serves the adaptive
+ * integrations -- integratePointsAdaptiveANT, density.py:211-273 (nested levels of 2, 6, 18, 54 ... nodes, only the
+ * new nodes of a level are evaluated) and the doubling grids of densityReal, :438-484 -- whose first levels are a
+ * handful of points each: evaluated level by level they are launch latency, evaluated together they are one launch.
+ * Every segment's sum equals negf_gr_int on that segment alone up to summation order. */
+int negf_gr_int_seg(negf_ctx* ctx, int handle, int m, const double* E_c128, const double* w_c128,
+                    int nseg, const int* seg_end, double* out_c128, int* info);
+
 /* sum_m w_m G Gamma_c G^H -- GrLessInt, integrate.py:177-208 (+ :74-82). */
 int negf_gless_int(negf_ctx* ctx, int handle, int ind, int m, const double* E_c128,
                    const double* w_c128, double* out_c128, int* info);
@@ -200,10 +209,13 @@ int negf_last_iters(negf_ctx* ctx, int handle, int m, int* iters, int* converged
  * the energy list of the launch; a launch that finds its key only forms Sigma = t g t^H with the provider's CURRENT
  * tau -- the last pass of the same kernel, so a hit equals a miss bit for bit, sweep counts and flags included.  The
  * key outlives providers: one re-created after setF, or the t = I variant behind surfG.g(), hits entries of its
- * predecessor.  Default: 8 grids; 0 switches the cache off and frees it (bench.py's headline runs cold that way).
- * Launches whose g would exceed 4 GB are not cached.  The *_dev entry points download their energy list (16 bytes
- * per point, one stream synchronisation) to form the key while the cache is on. */
+ * predecessor.  Defaults: 512 grids and 8 GB in all, least recently used entries evicted first (one SCF cycle at a
+ * fixed Fermi level is ~10^2 adaptive grids of 2 ... 324 points; BASELINE C3's 2000-point grid is 160 MB); 0 grids
+ * switches the cache off and frees it (bench.py's headline runs cold that way).  Launches whose g would exceed 4 GB
+ * are not cached.  The *_dev entry points download their energy list (16 bytes per point, one stream
+ * synchronisation) to form the key while the cache is on.  Environment: NEGF_CHAIN_CACHE=<grids> presets max_grids. */
 int negf_set_chain_cache(negf_ctx* ctx, int max_grids);
+int negf_set_chain_cache_bytes(negf_ctx* ctx, long long max_bytes);
 int negf_chain_cache_clear(negf_ctx* ctx);
 /* counters since negf_create; entries / bytes currently held (any pointer may be NULL) */
 int negf_chain_cache_stats(negf_ctx* ctx, long long* hits, long long* misses, long long* entries, long long* bytes);
@@ -223,6 +235,11 @@ int negf_profile_read_flops(negf_ctx* ctx, const char* family, double* flops_alg
 /* choose the inverse kernel: 0 = auto, 1 = unblocked Gauss-Jordan (any n),
  * 2 = blocked Gauss-Jordan with FP64 MFMA trailing updates */
 int negf_set_inverse_algo(negf_ctx* ctx, int algo);
+/* systems of n <= 96 orbitals: 0 = auto -- with negf_set_inverse_algo(0), E S - F - Sigma is assembled, inverted and
+ * (GrInt) accumulated in ONE kernel with the matrix held in the registers of a compute unit (no n x n work area in
+ * HBM; the SCF call pattern is ~10^2 integrals of 2 ... 324 points per density step, scfE.py:301-462); 1 = the
+ * assemble / inverse / accumulate kernel sequence through HBM that larger systems use (cross-check, A/B) */
+int negf_set_small_algo(negf_ctx* ctx, int algo);
 /* G Gamma G^H (integrate.py:81) and Tr[Gamma_L G Gamma_R G^H] (transport.py:156-157):
  * 0 = auto -- when the coupling matrices only touch the contact orbitals (CONST providers
  * with a small support, CHAIN1D / BETHE blocks without an orthogonalisation matrix) the

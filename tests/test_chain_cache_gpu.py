@@ -62,10 +62,10 @@ def test_chain1d_unequal_contacts_fixed_trip(engine, ncL, ncR):
 @pytest.fixture
 def cache(engine):
     engine.set_chain_cache(0)            # drop whatever earlier tests left
-    engine.set_chain_cache(8)
+    engine.set_chain_cache(512)
     yield engine
     engine.set_chain_cache(0)
-    engine.set_chain_cache(8)
+    engine.set_chain_cache(512)
 
 
 def _stats(engine):
@@ -97,7 +97,7 @@ def test_gcache_hit_equals_miss_bit_for_bit(cache, nc):
     eng.set_chain_cache(0)
     s0c, it0c, _ = g.sigma_batch(E, 0)
     sigc, itc, cvc = g.sigma_batch(E)
-    eng.set_chain_cache(8)
+    eng.set_chain_cache(512)
     assert np.array_equal(s0, s0c) and np.array_equal(sig, sigc) and np.array_equal(it, itc) and np.array_equal(cv, cvc)
     assert _stats(eng) == (h2 + 1, m2)                      # a switched-off cache counts nothing
 
@@ -124,7 +124,7 @@ def test_gcache_survives_setF_and_serves_the_t_identity_variant(cache):
     assert np.array_equal(itA, itB) and not np.array_equal(sigA, sigB)
     eng.set_chain_cache(0)
     sigC, itC, cvC = g.sigma_batch(E)                      # cold
-    eng.set_chain_cache(8)
+    eng.set_chain_cache(512)
     assert np.array_equal(sigB, sigC) and np.array_equal(itB, itC) and np.array_equal(cvB, cvC)
     # t = I: the surface Green's function itself, for a single energy (its own one-point entry, then a hit)
     g0 = g.g(E[3], 0)
@@ -202,7 +202,7 @@ def test_gcache_through_the_integrals_and_the_dev_entry_points(cache):
                 calculate_transmission(F, S, SigmaCalculator(g), np.real(E)))
     eng.set_chain_cache(0)
     cold = run()
-    eng.set_chain_cache(8)
+    eng.set_chain_cache(512)
     h, m = _stats(eng)
     warm = run()
     h1, m1 = _stats(eng)

@@ -186,7 +186,7 @@ def test_workspace_is_stable_across_entry_points(engine):
     a context the workspace is sized for that (contexts that only integrate keep the single-grid size)."""
     from gaunegf_amd.integrate import GrInt, GrLessInt
     from gaunegf_amd.transport import SigmaCalculator, calculate_transmission, calculate_dos
-    N = 72
+    N = 112                                               # (above 96: GrInt of a smaller system needs no workspace at all)
     F, S, g_dev, g_ref = _const_provider(N, 19)
     E = np.linspace(-1.0, 1.0, 37); w = np.full(37, 2.0 / 37)
     sc = SigmaCalculator(g_dev.sig[0], g_dev.sig[1])
@@ -562,7 +562,7 @@ def test_chain1d_order_predicted_for_new_grids(engine):
             assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
             assert it1.max() > it1.min()                        # (the jobs do differ in length)
     finally:
-        engine.set_chain_cache(8)
+        engine.set_chain_cache(512)
 
 
 @pytest.mark.parametrize("nc,eta", [(50, 1e-4), (64, 1e-3), (72, 1e-3)])
@@ -1066,7 +1066,7 @@ def test_config_C3_free_running_at_the_sweep_cap(engine):
         sig, iters, cv = g_dev.sigma_batch(E[sub])
         sig2, iters2, cv2 = g_dev.sigma_batch(E[sub])             # learned (longest-first) launch order
     finally:
-        engine.set_chain_cache(8)
+        engine.set_chain_cache(512)
     assert np.array_equal(iters, iters2) and np.array_equal(cv, cv2) and np.array_equal(sig, sig2)
     sig3, iters3, cv3 = g_dev.sigma_batch(E[sub])                 # fills the g(E) cache ...
     sig4, iters4, cv4 = g_dev.sigma_batch(E[sub])                 # ... and is served from it: the same bits again

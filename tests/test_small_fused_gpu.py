@@ -1,0 +1,199 @@
+"""
+Systems of n <= 96 orbitals on the GPU: the single-kernel path (assemble + Gauss-Jordan inverse + weighted sum with the
+matrix in registers, gaunegf_amd/csrc/k_small_fused.hip) against the numpy oracle and against the kernel sequence larger
+systems use (negf_set_small_algo(1)).  Reference: _gr_matrix_ops / _GInt, gauNEGF/integrate.py:67-142; utils.inv,
+utils.py:52-54.  Tolerance: 1e-8 relative Frobenius (observed ~1e-14).
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import MockSigma, chain_lead, const_sigma_pair, random_system, rel_fro
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def _const(N, seed):
+    from gaunegf_amd.surfGTester import surfGTest
+    F, S = random_system(N, seed)
+    nc = max(1, N // 10)
+    inds, _, _ = const_sigma_pair(N, S, nc, 0.1)
+    return F, S, surfGTest(F, S, inds, -0.1j), oracle.ConstSigma(F, S, inds, -0.1j)
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 31, 32, 33, 48, 60, 64, 65, 80, 81, 95, 96])
+def test_small_fused_G_and_integrals(engine, N):
+    """Every tile class (T = ceil(N / 16) = 1 ... 6), sizes on and next to the tile edges: G(E) itself (STORE mode),
+    GrInt (ACCUMULATE mode), GrLessInt and the DOS (STORE mode feeding the product / trace kernels), on the real axis
+    and off it, against the oracle; and the fused path against the kernel sequence."""
+    from gaunegf_amd.integrate import GrBatch, GrInt, GrLessInt
+    F, S, g, g_ref = _const(N, 40 + N)
+    E = np.concatenate([np.linspace(-2.5, 2.5, 9) + 1e-6j, [0.3 + 0.7j, -1.0 + 0.05j]])
+    w = np.linspace(0.5, 1.5, E.size) * (1 + 0.2j)
+    G = GrBatch(F, S, g, E)
+    for k, e in enumerate(E):
+        assert rel_fro(G[k], oracle.gr_point(g_ref.sigmaTot(e), e, F, S)) < TOL, (N, k)
+    a = GrInt(F, S, g, E, w)
+    assert rel_fro(a, oracle.GrInt(F, S, g_ref, E, w)) < TOL
+    b = GrLessInt(F, S, g, E, w, -1)
+    assert rel_fro(b, oracle.GrLessInt(F, S, g_ref, E, w, -1)) < TOL
+    engine.set_system(F, S)
+    tot = engine.dos(g._negf_lower(engine), E, per_site=False)
+    for k, e in enumerate(E):
+        assert abs(tot[k] - oracle.dos_at_energy(e, F, S, g_ref.sigmaTot(e))) < 1e-8 * max(1.0, abs(tot[k]))
+    assert np.array_equal(a, GrInt(F, S, g, E, w))                # bitwise reproducible
+    engine.set_small_algo(1)
+    try:
+        a1 = GrInt(F, S, g, E, w); G1 = GrBatch(F, S, g, E)
+    finally:
+        engine.set_small_algo(0)
+    assert rel_fro(a, a1) < 1e-12 and rel_fro(G, G1) < 1e-12
+
+
+def test_small_fused_many_points_and_chunks(engine):
+    """More energies than resident workgroups (a workgroup sums several points in its partial record) and more than one
+    chunk of 16384 points (chunk sums added in order); split-grid additivity and linearity in the weights."""
+    from gaunegf_amd.integrate import GrInt
+    F, S, g, g_ref = _const(20, 7)
+    rng = np.random.default_rng(3)
+    M = 3000
+    E = rng.uniform(-3, 3, M) + 1e-3j
+    w1 = rng.standard_normal(M); w2 = rng.standard_normal(M)
+    a = GrInt(F, S, g, E, w1); b = GrInt(F, S, g, E, w2)
+    assert rel_fro(GrInt(F, S, g, E, w1 + 2 * w2), a + 2 * b) < 1e-12
+    assert rel_fro(GrInt(F, S, g, E[:1111], w1[:1111]) + GrInt(F, S, g, E[1111:], w1[1111:]), a) < 1e-12
+    sub = np.arange(0, M, 37)
+    assert rel_fro(GrInt(F, S, g, E[sub], w1[sub]), oracle.GrInt(F, S, g_ref, E[sub], w1[sub])) < TOL
+    F4, S4, g4, g4_ref = _const(4, 9)
+    M = 40000
+    E = rng.uniform(-3, 3, M) + 1e-2j; w = rng.standard_normal(M)
+    big = GrInt(F4, S4, g4, E, w)
+    parts = sum(GrInt(F4, S4, g4, E[k:k + 10000], w[k:k + 10000]) for k in range(0, M, 10000))
+    assert rel_fro(big, parts) < 1e-12
+    assert rel_fro(GrInt(F4, S4, g4, E[::400], w[::400]), oracle.GrInt(F4, S4, g4_ref, E[::400], w[::400])) < TOL
+
+
+@pytest.mark.parametrize("N", [1, 17, 32, 60, 64, 96])
+def test_small_fused_singular_and_nan(engine, N):
+    """An exactly singular matrix and a NaN column in the middle of a batch: reported through info (1-based column),
+    the point NaN-filled, the neighbouring energies untouched -- the behaviour of the blocked kernels."""
+    from gaunegf_amd.integrate import GrBatch, GrInt
+
+    class Probe:
+        def __init__(self, bad): self.bad = bad
+        def sigmaTot(self, E):
+            z = np.zeros((N, N), dtype=complex)
+            if self.bad == "nan" and abs(E - 1.0) < 1e-12:
+                z[:, min(3, N - 1)] = np.nan
+            return z
+        def sigma(self, E, i): return np.zeros((N, N), dtype=complex)
+
+    S = np.eye(N)
+    Fz, _ = random_system(N, 7)
+    E = np.array([0.5 + 0.1j, 1.0 + 0j, 2.0 + 0.1j])
+    for bad, F in (("singular", np.eye(N)), ("nan", Fz)):
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            G = GrBatch(F, S, Probe(bad), E)
+        assert any("singular" in str(r.message) for r in rec), bad
+        assert np.all(np.isnan(G[1])), bad
+        assert engine.last_info[1] != 0 and engine.last_info[0] == 0 and engine.last_info[2] == 0
+        if bad == "singular":
+            assert engine.last_info[1] == 1
+        for k in (0, 2):
+            assert rel_fro(G[k], np.linalg.inv(E[k] * S - F)) < TOL, (bad, k)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            out = GrInt(F, S, Probe(bad), E, np.ones(3))
+        # (a block-diagonal F, S pair -- the singular case's F = S = 1 -- is integrated block by block and is exactly
+        #  zero between the blocks: the NaN point poisons the diagonal blocks)
+        assert np.all(np.isnan(np.diag(out)))
+        assert engine.last_info[1] != 0
+
+
+def test_small_fused_foreign_and_block_providers(engine):
+    """The other ways Sigma reaches the fused kernel: a host-evaluated provider (dense Sigma per energy), 1-D chain
+    leads (contact blocks subtracted through the position map, two contacts of different size) and a Bethe lattice."""
+    from gaunegf_amd.integrate import GrInt, GrLessInt
+    from gaunegf_amd.surfG1D import surfG
+    N = 30
+    F, S = random_system(N, 5)
+    rng = np.random.default_rng(2)
+    base = 0.05 * (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N)))
+    c0 = np.zeros((N, N), dtype=complex); c0[:4, :4] = -0.1j * np.eye(4)
+    g = MockSigma(base, [c0])
+    E, w = oracle.real_axis_grid(-2, 1, 17, 0.0)
+    assert rel_fro(GrInt(F, S, g, E, w), oracle.GrInt(F, S, g, E, w)) < TOL
+    assert rel_fro(GrLessInt(F, S, g, E, w, 0), oracle.GrLessInt(F, S, g, E, w, 0)) < TOL
+    # chain leads of 7 and 5 orbitals on a 40-orbital device
+    N = 40
+    F, S = random_system(N, 6)
+    aL = chain_lead(7, 61); aR = chain_lead(5, 62)
+    inds = [list(range(7)), list(range(N - 5, N))]
+    kw = dict(taus=[aL[2].copy(), aR[2].copy()], staus=[aL[3].copy(), aR[3].copy()], alphas=[aL[0], aR[0]],
+              aOverlaps=[aL[1], aR[1]], betas=[aL[2], aR[2]], bOverlaps=[aL[3], aR[3]], eta=1e-3)
+    gd = surfG(F, S, inds, **kw); gd.force_iters = 30
+    gr = oracle.Chain1DSigma(F, S, inds, kw["taus"], kw["staus"], kw["alphas"], kw["aOverlaps"], kw["betas"], kw["bOverlaps"],
+                             eta=1e-3); gr.force_iters = 30
+    E, w = oracle.bias_window_grid(-0.3, 0.3, 12, 300.0)
+    assert rel_fro(GrInt(F, S, gd, E, w), oracle.GrInt(F, S, gr, E, w)) < TOL
+    for ind in (None, 0, -1):
+        assert rel_fro(GrLessInt(F, S, gd, E, w, ind), oracle.GrLessInt(F, S, gr, E, w, ind)) < TOL
+    engine.set_small_algo(1)
+    try:
+        seq = GrInt(F, S, gd, E, w)
+    finally:
+        engine.set_small_algo(0)
+    assert rel_fro(GrInt(F, S, gd, E, w), seq) < 1e-12
+
+
+@pytest.mark.parametrize("N", [12, 60, 96, 130, 300])
+def test_segmented_integrals_equal_separate_calls(engine, N):
+    """negf_gr_int_seg: several GrInt integrals of one system from one pass (the levels an adaptive integration is about
+    to visit) -- every segment's sum equals the integral on that segment alone (up to summation order), through the
+    fused small-system path (N <= 96) and through the kernel sequence; an empty segment gives zeros."""
+    from gaunegf_amd.integrate import GrInt, GrIntSegments
+    F, S, g, g_ref = _const(N, 90 + N)
+    rng = np.random.default_rng(N)
+    sizes = [2, 4, 12, 0, 36, 7]
+    segs = [(rng.uniform(-2, 2, k) + 1j * rng.uniform(0.01, 1.0, k), rng.standard_normal(k) + 1j * rng.standard_normal(k))
+            for k in sizes]
+    got = GrIntSegments(F, S, g, segs)
+    assert len(got) == len(segs)
+    for (E, w), a in zip(segs, got):
+        if E.size == 0:
+            assert not np.any(a)
+            continue
+        assert rel_fro(a, GrInt(F, S, g, E, w)) < 1e-12
+    assert rel_fro(got[2], oracle.GrInt(F, S, g_ref, *segs[2])) < TOL
+    again = GrIntSegments(F, S, g, segs)
+    assert all(np.array_equal(a, b) for a, b in zip(got, again))
+
+
+def test_adaptive_integrations_with_and_without_speculation(engine, capsys):
+    """densityComplex / densityReal evaluate the levels they are about to visit together (density.SPECULATIVE_POINTS);
+    level by level (the reference's call sequence) they must return the same density to rounding, and both equal the
+    oracle-served run of the same driver."""
+    from gaunegf_amd import density as D
+    F, S, g, g_ref = _const(24, 5)
+    args = (F, S, g, -6.0, 0.2)
+    spec = D.densityComplex(*args, tol=1e-6, T=300.0), D.densityReal(F, S, g, -40.0, -6.0, tol=1e-6, T=0)
+    old = D.SPECULATIVE_POINTS
+    D.SPECULATIVE_POINTS = 0
+    try:
+        plain = D.densityComplex(*args, tol=1e-6, T=300.0), D.densityReal(F, S, g, -40.0, -6.0, tol=1e-6, T=0)
+    finally:
+        D.SPECULATIVE_POINTS = old
+    for a, b in zip(spec, plain):
+        assert rel_fro(a, b) < 1e-12
+    saved = D.GrInt
+    D.GrInt = oracle.GrInt
+    try:
+        ref = D.densityComplex(F, S, g_ref, -6.0, 0.2, tol=1e-6, T=300.0), D.densityReal(F, S, g_ref, -40.0, -6.0, tol=1e-6, T=0)
+    finally:
+        D.GrInt = saved
+    for a, b in zip(spec, ref):
+        assert rel_fro(a, b) < TOL
