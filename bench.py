@@ -392,7 +392,7 @@ def worker_c3(args):
     # warm steps: the same integral with the g(E) cache on -- one step fills it, the next ones only form
     # Sigma = t g t^H; bit-identical result (asserted); NOT the headline
     warm = None
-    if world == 1:
+    if world == 1 and not args.no_warm:
         eng.set_chain_cache(512)
         step(); fence()
         eng.profile(True); eng.profile_reset()
@@ -862,6 +862,8 @@ def main():
                     help="c4 / c5 on one GPU: run only rank 0's share of a K-way energy-cyclic sharding (the small per-GPU batches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="skip the N_orb=500 x 1000 and C2 secondary lines")
+    ap.add_argument("--no-warm", action="store_true", help="skip the warm (g(E) cache on) steps after the timed cold ones: "
+                    "profiler runs, whose per-kernel averages should hold the cold launches only")
     ap.add_argument("--no-whole-host", action="store_true", help="skip the CPU pools over ALL usable CPUs (keep the 16-process ones)")
     ap.add_argument("--cpu-budget", type=float, default=18.0, help="seconds of CPU work for the headline baseline")
     args = ap.parse_args()

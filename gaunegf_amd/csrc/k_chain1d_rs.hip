@@ -51,6 +51,11 @@ constexpr int RS_NB = RS_PANEL;           // panel width of the small inverse: h
 #ifndef RS_ROW_MODE
 #define RS_ROW_MODE 0                 // pivot row of the factoring wave: 0 LDS line (round 2), 1 v_readlane, 2 ds_bpermute
 #endif
+#ifndef RS_LA_FLAGS
+#define RS_LA_FLAGS 0                 // look-ahead of the small inverse synchronised by two workgroup barriers (0) or by LDS counters
+                                      // (1: built and measured in round 4 -- parity green, the C3 launch 666 ms against 668: with
+                                      // three workgroups per CU a barrier's wait is another workgroup's issue slot, not idle time)
+#endif
 #ifndef RS_STAMPS
 #define RS_STAMPS 0                   // 1: diagnostic build -- the phase / cycle stamps of NEGF_CHAIN_STAMPS=1 are compiled in
 #endif                                //    (NEGF_EXTRA_HIPCC_FLAGS=-DRS_STAMPS=1 python -m gaunegf_amd.build --force); the production
@@ -300,9 +305,16 @@ __device__ __forceinline__ void rs_load_qf(const cplx* W, const int* pivrow, int
 }
 
 // one tile (ti, tj): a full 16 x 16 tile, or a row / column strip (one value per lane, corner: one block)
+__device__ __forceinline__ void rs_wait_count(const unsigned* cnt, unsigned target)
+{
+    // (LDS counter of the look-ahead, see rs_inverse: spins only while another wave of the workgroup is behind)
+    while (*reinterpret_cast<const volatile unsigned*>(cnt) < target) __builtin_amdgcn_s_sleep(1);
+}
+
 template <int P, int NKS, int TR>
 __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof, int ti, int tj, int p0, int pw,
-                                               int fi, int fk, const cplx (&qf)[NKS], int clo, int chi /* columns [clo, chi) are stored */)
+                                               int fi, int fk, const cplx (&qf)[NKS], int clo, int chi /* columns [clo, chi) are stored */,
+                                               const unsigned* wait_cnt = nullptr, unsigned wait_target = 0 /* stores wait for *wait_cnt >= wait_target */)
 {
     const bool rowstrip = TR >= 0 && ti == TR, colstrip = TR >= 0 && tj == TR;
     if (!rowstrip && !colstrip) {
@@ -326,6 +338,7 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
             if (M3) mfma3(ua, ub, uc, pa[ks].x, pa[ks].y, pa[ks].x + pa[ks].y, qf[ks].x, qf[ks].y, qf[ks].x + qf[ks].y);
             else zmfma(ua, uc, pa[ks], qf[ks]);
         }
+        if (wait_cnt) rs_wait_count(wait_cnt, wait_target);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = ti * 16 + fk + 4 * r;
@@ -348,6 +361,7 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
             mfma3s(ua, ub, uc, pa[ks].x, pa[ks].y, pa[ks].x + pa[ks].y, qf[ks].x, qf[ks].y, qf[ks].x + qf[ks].y);
+        if (wait_cnt) rs_wait_count(wait_cnt, wait_target);
         if (mine && row < n && col < n && col >= clo && col < chi) *cptr = cmake(ua - ub, uc - ua - ub);
     }
 }
@@ -424,6 +438,7 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
 template <int T16, int P, int TR>
 __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* colof, cplx* rowline, int tid,
                                            int wave /* role number of this wave, see rs_wave_role */, bool fixed_fw,
+                                           unsigned* la_cnt /* [2] LDS */, unsigned& la_epoch,
                                            unsigned long long* st = nullptr)
 {
     const int lane = tid & 63;
@@ -444,9 +459,23 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
             const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
             cplx qf[RS_NB / 4];
             rs_load_qf<P, RS_NB / 4, TR>(W, pivrow, tl, p0, pw, fi, fk, qf);
+#if RS_LA_FLAGS
+            // No workgroup barrier in the look-ahead (there were two, seven times a sweep): two LDS counters instead.
+            // la_cnt[0] counts the waves whose Q fragment -- the panel's pivot rows in the next panel's columns, rows that
+            // other waves are about to overwrite -- is on its way (a wave's LDS operations execute in order, so its
+            // counter increment is behind its reads); a wave stores its look-ahead tile only when all four are.
+            // la_cnt[1] counts the waves that have stored; only the FACTORING wave waits for it -- the others go straight
+            // on to the trailing update, which touches neither the next panel's columns nor anybody else's pivot rows.
+            la_epoch += RS_WAVES;
+            if (lane == 0) atomicAdd(&la_cnt[0], 1u);
+            if (wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, tl, p0, pw, fi, fk, qf, n0, n0 + RS_NB, &la_cnt[0], la_epoch);
+            if (lane == 0) atomicAdd(&la_cnt[1], 1u);
+            if (wave == fw) rs_wait_count(&la_cnt[1], la_epoch);
+#else
             __syncthreads();
             if (wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, tl, p0, pw, fi, fk, qf, n0, n0 + RS_NB);
             __syncthreads();
+#endif
         }
         if (has_cur) {
             // the other columns, tile by tile, one owner per tile (the owner reads its Q fragment before it writes):
@@ -511,6 +540,9 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     __shared__ int flags[2 * RS_WAVES];                 // per wave: any(diff > conv), all(diff <= conv)
     __shared__ int pivrow[64], colof[64];
     __shared__ cplx rowline[RS_NB];                     // pivot row of the column step being factored
+    __shared__ unsigned la_cnt[2];                      // look-ahead counters of rs_inverse
+    unsigned la_epoch = 0;
+    if (threadIdx.x == 0) { la_cnt[0] = 0u; la_cnt[1] = 0u; }
 
     // job of this launch slot: in launch order, or -- when the provider has seen this grid before -- in
     // the order of decreasing sweep counts of the previous evaluation (the jobs differ by up to 20x in
@@ -812,7 +844,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         unsigned long long* st = (RS_STAMPS && a.stamps && job == 0 && count == a.stamp_sweep) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
         if (!gc_hit) {
-            rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
+            rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, la_cnt, la_epoch, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
             if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
             gather_mix(first, st);
             if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();

@@ -1183,3 +1183,29 @@ def test_config_C5_shape(engine):
         tot, comp = oracle.transmission_spin_block(e, F, S, sig[0] + sig[1], g1, g2)
         assert np.max(np.abs(Ts[k] - comp)) < TOL * max(1.0, np.max(np.abs(comp)))
         assert abs(T[k] - tot) < TOL * max(1.0, abs(tot))
+
+
+@pytest.mark.parametrize("N", [60, 120, 300])
+def test_imaginary_part_of_the_real_axis_integral(engine, N):
+    """The dense kernels form complex products from three real ones (3M: Im = S3 - S1 - S2), whose rounding error in the
+    imaginary part is relative to |Re|, not to |Im|.  On a real-axis grid at eta = 1e-6 with weakly coupled contacts the
+    density lives in Im G, orders of magnitude below Re G: the imaginary part ALONE of GrInt and of G(E) must still meet
+    the 1e-8 bar against the oracle (N = 60: the fused small-system kernel; 120: the single-workgroup blocked inverse;
+    300: the windowed inverse with its 3M column updates)."""
+    from gaunegf_amd.integrate import GrBatch, GrInt
+    from gaunegf_amd.surfGTester import surfGTest
+    F, S = random_system(N, 31 + N)
+    nc = max(2, N // 20)
+    inds = [list(range(nc)), list(range(N - nc, N))]
+    g_dev = surfGTest(F, S, inds, -1e-4j)
+    g_ref = oracle.ConstSigma(F, S, inds, -1e-4j)
+    E = np.linspace(-2.0, 2.0, 24) + 1e-6j
+    w = np.full(24, 4.0 / 24)
+    ref = oracle.GrInt(F, S, g_ref, E, w)
+    got = GrInt(F, S, g_dev, E, w)
+    assert np.linalg.norm(ref.imag) < 1e-1 * np.linalg.norm(ref.real)          # (the regime the test is about: Im << Re)
+    assert rel_fro(got.imag, ref.imag) < TOL
+    G = GrBatch(F, S, g_dev, E[:3])
+    for k in range(3):
+        r = oracle.gr_point(g_ref.sigmaTot(E[k]), E[k], F, S)
+        assert rel_fro(G[k].imag, r.imag) < TOL, k
