@@ -714,6 +714,11 @@ def worker_scf(args):
     # schedules one GPU's share of them, and 256 BLAS threads on that turn a 200 x 200 solve into 90 ms
     limits = _blas_limits()
     blas_ctx = limits(limits=max(1, min(host_cpus(), int(os.environ.get("NEGF_BENCH_CPU_WORKERS", "16"))))) if limits else None
+    # the interpreter holds ~10^6 objects once torch is imported; a full garbage collection over them costs tens of
+    # milliseconds and lands in whatever small step happens to allocate at that moment: move what exists now into the
+    # permanent generation (the collector stays on for everything allocated from here)
+    import gc
+    gc.collect(); gc.freeze()
     for name in names:
         label, F, S, g, make_ref, ne, Eminf = _scf_system(name)
         qV, T, tol = 0.1, 300.0, 1e-4

@@ -27,6 +27,8 @@
 // Exactly singular / NaN columns: info[m] = 1-based column, the point's G is NaN-filled (as the blocked kernels do).
 #include "negf_common.h"
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -260,6 +262,201 @@ __global__ __launch_bounds__(SF_THREADS) void small_fused_kernel(SmallFusedArgs 
     }
 }
 
+// ---- second layout (round 4, later; the default): COLUMNS PER WAVE, ROWS PER LANE.  Wave w owns the columns
+// [w CPW, (w+1) CPW), lane l the rows l and l + 64 (RPL = 1 for n <= 64): the tile W[RPL][CPW] is again in registers
+// with static indices, because the pivot steps run as  for (owner wave) for (c = 0 .. CPW-1, unrolled)  -- step
+// k = owner * CPW + c.
+//   * the pivot column k lies in ONE wave: its owner finds the pivot alone (lane = row: DPP maximum, no exchange at
+//     all), publishes the column and p to LDS -- ONE workgroup barrier per step (the 16 x 16 thread-grid layout above
+//     needs two: there column and row are both spread over all waves);
+//   * the pivot row's entries in a wave's own columns are in that wave's lane p: a wave-local LDS line (written by one
+//     lane, read by all, no barrier -- a wave's LDS operations execute in order), as in the chain kernel's rs_factor;
+//   * the update is select-free: multipliers f_i = c_i / pivot for i != p and f_p = 1 - 1 / pivot (row p then becomes
+//     row_p / pivot by the same formula), column k reset to the unit vector e_p beforehand, so every lane runs
+//     RPL x CPW complex FMAs on the RAW pivot row: ~150 vector instructions per step and wave against ~350.
+// The matrix is assembled into LDS with coalesced reads first (same operation order as the tile layout), the
+// un-permuted inverse goes back to LDS, and the accumulate / store phases are those of the tile layout.
+template <int RPL, int CPW>
+__global__ __launch_bounds__(SF_THREADS) void small_cw_kernel(SmallFusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+    cplx* Gs = reinterpret_cast<cplx*>(sf_smem);                  // [n][gp]: the assembled matrix, later the un-permuted inverse
+    __shared__ cplx colb[2][128];                                 // pivot column, double buffered by step parity
+    __shared__ cplx rowl[4][CPW];                                 // per wave: the pivot row in the wave's columns
+    __shared__ int piv_s[2];                                      // pivot row of the step, by parity
+    __shared__ int bad_s;
+    __shared__ int pivrow_s[SF_MAXN], colof_s[SF_MAXN];
+
+    const int n = a.n, gp = a.gp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int T16 = (n + 15) >> 4;
+    const int col0 = wave * CPW;
+    cplx* part = a.Gout ? nullptr : a.partial + (size_t)blockIdx.x * n * n;
+    bool first = true;
+
+    for (int e = blockIdx.x; e < a.m; e += gridDim.x) {
+        // ---- assemble: (E S - H) - Sigma in the reference's order (integrate.py:70), contact blocks one contact after
+        // the other, as scatter_sub_kernel subtracts them; coalesced (thread (ty, tx) walks 16 x 16 patches)
+        const cplx z = a.E[e];
+        if (tid == 0) bad_s = 0;
+        for (int r = 0; r < T16; ++r)
+            for (int c = 0; c < T16; ++c) {
+                const int i = ty + 16 * r, j = tx + 16 * c;
+                if (i < n && j < n) {
+                    const int o = i * n + j;
+                    const cplx s_ = a.S[o], h = a.H[o];
+                    cplx v = cmake(z.x * s_.x - z.y * s_.y - h.x, z.x * s_.y + z.y * s_.x - h.y);
+                    if (a.sig_dense) v = csub(v, a.sig_dense[(size_t)e * a.sig_stride + o]);
+                    for (int ct = 0; ct < a.n_contacts; ++ct) {
+                        const int pi = a.pos[ct * n + i], pj = a.pos[ct * n + j];
+                        if (pi >= 0 && pj >= 0)
+                            v = csub(v, a.blk[(size_t)e * a.blk_stride + a.blk_off[ct] + pi * a.nc[ct] + pj]);
+                    }
+                    Gs[i * gp + j] = v;
+                }
+            }
+        __syncthreads();
+        cplx W[RPL][CPW];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int i = lane + 64 * r, j = col0 + c;
+                W[r][c] = (i < n && j < n) ? Gs[i * gp + j] : cmake(0.0, 0.0);
+            }
+        bool used[RPL];                                           // this lane's rows that have been pivots
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) used[r] = false;
+        __syncthreads();                                          // Gs is free again (it receives the result below)
+
+        // ---- Gauss-Jordan, implicit partial pivoting, one barrier per step
+        for (int ow = 0; ow < 4; ++ow) {
+            if (ow * CPW >= n) break;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int k = ow * CPW + c;
+                if (k < n) {                                      // (uniform; the steps beyond n fall away at the tail)
+                    const int buf = k & 1;
+                    if (wave == ow) {
+                        // owner: pivot search on its own registers.  |re| + |im| >= 0 orders like its bit pattern: wave
+                        // maximum of the high words, then of the low words among the lanes that hold it; lowest row wins
+                        unsigned h_[RPL], l_[RPL];
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) {
+                            const double v = cabs1(W[r][c]);
+                            const bool ok = lane + 64 * r < n && !used[r] && v > 0.0;
+                            h_[r] = ok ? (unsigned)__double2hiint(v) : 0u;
+                            l_[r] = ok ? (unsigned)__double2loint(v) : 0u;
+                        }
+                        unsigned hmax = h_[0];
+                        if (RPL == 2) hmax = h_[RPL - 1] > hmax ? h_[RPL - 1] : hmax;
+                        const unsigned hm = sf_wave_max_u32(hmax);
+                        unsigned lcand = h_[0] == hm ? l_[0] : 0u;
+                        if (RPL == 2) { const unsigned l1 = h_[RPL - 1] == hm ? l_[RPL - 1] : 0u; lcand = l1 > lcand ? l1 : lcand; }
+                        const unsigned lm = sf_wave_max_u32(lcand);
+                        int p;
+                        if (hm != 0u || lm != 0u) {
+                            const unsigned long long b0 = __ballot(h_[0] == hm && l_[0] == lm);
+                            const unsigned long long b1 = RPL == 2 ? __ballot(h_[RPL - 1] == hm && l_[RPL - 1] == lm) : 0ull;
+                            p = b0 ? (int)__ffsll((long long)b0) - 1 : 64 + (int)__ffsll((long long)b1) - 1;
+                        } else {                                  // exactly singular or NaN column: lowest unused row
+                            const unsigned long long f0 = __ballot(lane < n && !used[0]);
+                            const unsigned long long f1 = RPL == 2 ? __ballot(lane + 64 < n && !used[RPL - 1]) : 0ull;
+                            p = f0 ? (int)__ffsll((long long)f0) - 1 : 64 + (int)__ffsll((long long)f1) - 1;
+                            if (lane == 0) atomicCAS(&bad_s, 0, k + 1);
+                        }
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) colb[buf][lane + 64 * r] = W[r][c];
+                        if (lane == 0) { piv_s[buf] = p; pivrow_s[k] = p; colof_s[p] = k; }
+                    }
+                    __syncthreads();
+                    const int p = piv_s[buf];
+                    const int pl = p & 63, pr = p >> 6;
+                    // 1 / pivot = conj(pivot) / |pivot|^2 by v_rcp_f64 and two Newton steps
+                    const cplx pv = colb[buf][p];
+                    const double pd = pv.x * pv.x + pv.y * pv.y;
+                    double sc = __builtin_amdgcn_rcp(pd);
+                    sc = fma(sc, fma(-pd, sc, 1.0), sc);
+                    sc = fma(sc, fma(-pd, sc, 1.0), sc);
+                    const cplx ip = cmake(pv.x * sc, -pv.y * sc);
+                    // the pivot row in this wave's columns: lane pl writes, all read (wave-local line)
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == pl) {
+#pragma unroll
+                        for (int cc = 0; cc < CPW; ++cc) {
+                            const cplx v = (RPL == 2 && pr) ? W[RPL - 1][cc] : W[0][cc];
+                            // (in the owner wave column k is about to become the unit vector e_p: its entry in row p is 1)
+                            rowl[wave][cc] = (wave == ow && cc == c) ? cmake(1.0, 0.0) : v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    cplx f[RPL];
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r) {
+                        const int i = lane + 64 * r;
+                        const cplx cv = colb[buf][i];             // (rows >= n hold zeros: published by the owner)
+                        const cplx m_ = cmul(cv, ip);
+                        const bool isp = i == p;
+                        f[r] = cmake(isp ? 1.0 - ip.x : m_.x, isp ? -ip.y : m_.y);
+                        used[r] = used[r] || isp;
+                    }
+                    if (wave == ow) {
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) W[r][c] = cmake(lane + 64 * r == p ? 1.0 : 0.0, 0.0);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < CPW; ++cc) {
+                        const cplx rb = rowl[wave][cc];
+#pragma unroll
+                        for (int r = 0; r < RPL; ++r) W[r][cc] = cfnma(W[r][cc], f[r], rb);
+                    }
+                }
+            }
+        }
+        // ---- un-permute through LDS: W[r][c] is G[colof[r]][pivrow[c]]  (pivrow / colof / bad_s are complete: every
+        // step's owner wrote them in front of that step's barrier)
+        const int bad = bad_s;
+        const double qnan = __builtin_nan("");
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const int i = lane + 64 * r;
+            if (i < n) {
+                const int gi = colof_s[i];
+#pragma unroll
+                for (int c = 0; c < CPW; ++c) {
+                    const int j = col0 + c;
+                    if (j < n) Gs[gi * gp + pivrow_s[j]] = bad ? cmake(qnan, qnan) : W[r][c];
+                }
+            }
+        }
+        if (tid == 0 && a.info) a.info[e] = bad;
+        __syncthreads();
+        if (a.Gout) {
+            cplx* out = a.Gout + (size_t)e * a.g_stride;
+            for (int r = 0; r < T16; ++r)
+                for (int c = 0; c < T16; ++c) {
+                    const int i = ty + 16 * r, j = tx + 16 * c;
+                    if (i < n && j < n) out[i * n + j] = Gs[i * gp + j];
+                }
+        } else {
+            const cplx w = a.w[e];
+            for (int r = 0; r < T16; ++r)
+                for (int c = 0; c < T16; ++c) {
+                    const int i = ty + 16 * r, j = tx + 16 * c;
+                    if (i < n && j < n) {
+                        const cplx old = first ? cmake(0.0, 0.0) : part[i * n + j];
+                        part[i * n + j] = cfma(old, w, Gs[i * gp + j]);      // acc += w G, as accumulate_partial_kernel
+                    }
+                }
+            first = false;
+        }
+        __syncthreads();                                          // Gs, the pivot tables and the buffers are reused
+    }
+}
+
 // out[i] = sum over the workgroups' partial sums, in workgroup order (fixed -> reproducible).  256 threads = 32
 // elements x 8 segments of the workgroup range; the segment sums are combined in segment order.
 __global__ __launch_bounds__(256) void small_reduce_kernel(int n2, int parts, const cplx* __restrict__ partial,
@@ -281,6 +478,18 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(int n2, int parts, co
         for (int q = 1; q < 8; ++q) t = cadd(t, seg[q][el]);
         out[i] = t;
     }
+}
+
+template <int RPL, int CPW>
+void cw_launch(hipStream_t st, const SmallFusedArgs& a, int grid, size_t smem)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_cw_kernel<RPL, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess) (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((small_cw_kernel<RPL, CPW>), dim3(grid), dim3(SF_THREADS), smem, st, a);
 }
 
 template <int T>
@@ -315,7 +524,17 @@ void launch_small_fused(hipStream_t st, SmallFusedArgs a)
     // segments (a.nseg > 0): one workgroup and one partial record per energy, summed per segment below
     const int grid = a.nseg > 0 ? a.m : small_fused_grid(a.n, a.m);
     const int T = (a.n + 15) / 16;
-    switch (T) {
+    static int layout = -1;                       // NEGF_SMALL_KERNEL=tile: the 16 x 16 thread-grid layout (A/B, cross-check)
+    if (layout < 0) { const char* e = getenv("NEGF_SMALL_KERNEL"); layout = (e && strcmp(e, "tile") == 0) ? 1 : 0; }
+    if (layout == 0) switch (T) {
+    case 1: cw_launch<1, 4>(st, a, grid, smem); break;
+    case 2: cw_launch<1, 8>(st, a, grid, smem); break;
+    case 3: cw_launch<1, 12>(st, a, grid, smem); break;
+    case 4: cw_launch<1, 16>(st, a, grid, smem); break;
+    case 5: cw_launch<2, 20>(st, a, grid, smem); break;
+    default: cw_launch<2, 24>(st, a, grid, smem); break;
+    }
+    else switch (T) {
     case 1: sf_launch<1>(st, a, grid, smem); break;
     case 2: sf_launch<2>(st, a, grid, smem); break;
     case 3: sf_launch<3>(st, a, grid, smem); break;

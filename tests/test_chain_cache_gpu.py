@@ -236,3 +236,28 @@ def test_gcache_through_the_integrals_and_the_dev_entry_points(cache):
     finally:
         for b in (Ed, wd, outd):
             hip.hipFree(b)
+
+
+def test_gcache_byte_budget(cache):
+    """The cache is bounded in bytes as well as in entries: with room for two of three equally large launches the least
+    recently used one goes, and a launch larger than the whole budget is simply not cached."""
+    eng = cache
+    nc = 16
+    F, S, g, _, _ = _two_lead_system(50, nc, nc, 1300, 1e-3)
+    grids = [np.linspace(-1, 1, 40) + 0.01 * k for k in range(3)]
+    per = 40 * 2 * nc * nc * 16 + 2 * 40 * 2 * 4                # bytes of one entry: g blocks + counts and flags
+    eng.set_chain_cache(max_bytes=2 * per + 64)
+    try:
+        h, m = _stats(eng)
+        ref = [g.sigma_batch(E)[0] for E in grids]               # third insertion evicts the first
+        assert _stats(eng) == (h, m + 3) and eng.chain_cache_stats()["entries"] == 2
+        assert np.array_equal(g.sigma_batch(grids[2])[0], ref[2]) and np.array_equal(g.sigma_batch(grids[1])[0], ref[1])
+        assert _stats(eng) == (h + 2, m + 3)
+        assert np.array_equal(g.sigma_batch(grids[0])[0], ref[0])
+        assert _stats(eng) == (h + 2, m + 4)
+        eng.set_chain_cache(max_bytes=per // 2)                  # nothing of this size fits any more
+        eng.chain_cache_clear()
+        g.sigma_batch(grids[0]); g.sigma_batch(grids[0])
+        assert eng.chain_cache_stats()["entries"] == 0
+    finally:
+        eng.set_chain_cache(max_bytes=8 << 30)

@@ -197,3 +197,54 @@ def test_adaptive_integrations_with_and_without_speculation(engine, capsys):
         D.GrInt = saved
     for a, b in zip(spec, ref):
         assert rel_fro(a, b) < TOL
+
+
+def test_segment_and_cache_argument_checks(engine):
+    """Error behaviour of the round-4 entry points: malformed segment tables are NEGF_EINVAL, not a launch; the cache
+    knobs reject negative values; the byte budget evicts like the entry count does."""
+    import ctypes as C
+    from gaunegf_amd._lib import NegfError, NEGF_EINVAL
+    F, S, g, _ = _const(10, 3)
+    engine.set_system(F, S)
+    h = g._negf_lower(engine)
+    E = np.ascontiguousarray(np.linspace(-1, 1, 6) + 0.1j); w = np.ascontiguousarray(np.ones(6, dtype=complex))
+    out = np.zeros((2, 10, 10), dtype=complex)
+    lib, ctx = engine._lib, engine._ctx
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for ends in ([4, 5], [4, 3], [7, 6], [-1, 6]):            # last != m, decreasing, beyond m, negative
+        se = np.ascontiguousarray(ends, dtype=np.int32)
+        assert lib.negf_gr_int_seg(ctx, h, 6, vp(E), vp(w), 2, vp(se), vp(out), None) == NEGF_EINVAL, ends
+    se = np.ascontiguousarray([2, 6], dtype=np.int32)
+    assert lib.negf_gr_int_seg(ctx, h, 6, vp(E), vp(w), 0, vp(se), vp(out), None) == NEGF_EINVAL
+    assert lib.negf_gr_int_seg(ctx, h, 6, vp(E), vp(w), 2, vp(se), vp(out), None) == 0
+    with pytest.raises(NegfError):
+        engine.set_chain_cache(-1)
+    with pytest.raises(NegfError):
+        engine.set_chain_cache(max_bytes=-5)
+    with pytest.raises(NegfError):
+        engine.set_small_algo(7)
+
+
+def test_tile_layout_kernel_in_a_fresh_process():
+    """NEGF_SMALL_KERNEL=tile selects the first layout of the small-system kernel (16 x 16 thread grid, two barriers per
+    pivot step; the default is columns-per-wave with one): kept as an A/B and a cross-check, so it must stay correct."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import oracle
+        from test_small_fused_gpu import _const
+        from helpers import rel_fro
+        from gaunegf_amd.integrate import GrBatch, GrInt
+        for N in (1, 17, 60, 81, 96):
+            F, S, g, g_ref = _const(N, 40 + N)
+            E = np.concatenate([np.linspace(-2.5, 2.5, 5) + 1e-6j, [0.3 + 0.7j]]); w = np.linspace(0.5, 1.5, E.size) * (1 + 0.2j)
+            G = GrBatch(F, S, g, E)
+            for k, e in enumerate(E):
+                assert rel_fro(G[k], oracle.gr_point(g_ref.sigmaTot(e), e, F, S)) < 1e-8, (N, k)
+            assert rel_fro(GrInt(F, S, g, E, w), oracle.GrInt(F, S, g_ref, E, w)) < 1e-8
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEGF_SMALL_KERNEL="tile")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
