@@ -1111,24 +1111,25 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
     return NEGF_OK;
 }
 
-int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_dev,
-                       const double* w_dev, double* out_dev)
+// sum_m w_m G Gamma_c G^H over the energies E[0..m) (device pointers).  nseg == 0: one sum into out [n*n]; nseg > 0: the
+// energies are nseg consecutive segments ending at seg_end[s] (host array) and out [nseg][n*n] receives one sum each.
+static int gless_core(negf_ctx* c, SigmaProvider* p, int contact, int m, const cplx* E, const cplx* w, cplx* out,
+                      int nseg, const int* seg_end)
 {
-    SigmaProvider* p = get_provider(c, handle);
-    int rc = check_ready(c, p, m);
-    if (rc) return rc;
-    if (!out_dev || (m > 0 && (!E_dev || !w_dev))) return NEGF_EINVAL;
-    const int contact = norm_contact(p, ind);
-    if (contact == -2) return NEGF_EINVAL;
-    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    int rc;
     const size_t n2 = (size_t)c->n * c->n;
     const int n = c->n;
     if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
     if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
-    const cplx* E = reinterpret_cast<const cplx*>(E_dev);
-    const cplx* w = reinterpret_cast<const cplx*>(w_dev);
-    cplx* out = reinterpret_cast<cplx*>(out_dev);
-    NEGF_HIP_CHECK(hipMemsetAsync(out, 0, n2 * sizeof(cplx), c->stream));
+    NEGF_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)std::max(nseg, 1) * n2 * sizeof(cplx), c->stream));
+    auto accumulate = [&](const cplx* X, int m0, int nb) {
+        ProfScope ps(c, "accumulate");
+        if (nseg == 0) { launch_accumulate(c->stream, (int)n2, nb, w + m0, X, out, c->W2); return; }
+        for (int sg = 0, start = 0; sg < nseg; start = seg_end[sg], ++sg) {
+            const int lo = std::max(start, m0), hi = std::min(seg_end[sg], m0 + nb);
+            if (hi > lo) launch_accumulate(c->stream, (int)n2, hi - lo, w + lo, X + (size_t)(lo - m0) * n2, out + (size_t)sg * n2, c->W2);
+        }
+    };
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
         if ((rc = run_assemble_inverse(c, p, m0, nb, E))) return rc;
@@ -1144,8 +1145,7 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
                 launch_zgemm(c->stream, n, g.K, g.K, nb, Gc, g.K, n2, g.mat, g.K, g.stride, 0, X, g.K, n2);
                 launch_zgemm(c->stream, n, n, g.K, nb, X, g.K, n2, Gc, g.K, n2, 3, c->W1, n, n2);   // Hermitian result
             }
-            ProfScope ps(c, "accumulate");
-            launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);
+            accumulate(c->W1, m0, nb);
             continue;
         }
         size_t gs = 0;
@@ -1161,12 +1161,25 @@ int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_
             launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2,
                          (p->kind == SK_PRECOMPUTED && p->pre_is_gamma) ? 1 : 3, c->W1, n, n2);
         }
-        ProfScope ps(c, "accumulate");
-        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->W1, out, c->W2);
+        accumulate(c->W1, m0, nb);
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
     return NEGF_OK;
+}
+
+int negf_gless_int_dev(negf_ctx* c, int handle, int ind, int m, const double* E_dev,
+                       const double* w_dev, double* out_dev)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out_dev || (m > 0 && (!E_dev || !w_dev))) return NEGF_EINVAL;
+    const int contact = norm_contact(p, ind);
+    if (contact == -2) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    return gless_core(c, p, contact, m, reinterpret_cast<const cplx*>(E_dev), reinterpret_cast<const cplx*>(w_dev),
+                      reinterpret_cast<cplx*>(out_dev), 0, nullptr);
 }
 
 int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R, int spin_mode,
@@ -1416,6 +1429,40 @@ int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const doubl
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
     // one download of all segment sums and the info, one synchronisation
+    unsigned char* pout = c->h_pin + 2 * (size_t)m * sizeof(cplx);
+    int* pinfo = reinterpret_cast<int*>(pout + nseg * n2 * sizeof(cplx));
+    NEGF_HIP_CHECK(hipMemcpyAsync(pout, c->d_seg_out, nseg * n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));
+    if (m > 0) NEGF_HIP_CHECK(hipMemcpyAsync(pinfo, c->d_info, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    std::memcpy(out, pout, nseg * n2 * sizeof(cplx));
+    rc = NEGF_OK;
+    for (int i = 0; i < m; ++i) { if (info) info[i] = pinfo[i]; if (pinfo[i] != 0) rc = NEGF_ESINGULAR; }
+    return rc;
+}
+
+// the same for GrLessInt (the adaptive bias-window integral, densityGrid, density.py:605-658)
+int negf_gless_int_seg(negf_ctx* c, int handle, int ind, int m, const double* E, const double* w, int nseg,
+                       const int* seg_end, double* out, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out || nseg <= 0 || !seg_end || (m > 0 && (!E || !w))) return NEGF_EINVAL;
+    for (int sg = 0, prev = 0; sg < nseg; ++sg) { if (seg_end[sg] < prev || seg_end[sg] > m) return NEGF_EINVAL; prev = seg_end[sg]; }
+    if (seg_end[nseg - 1] != m) return NEGF_EINVAL;
+    const int contact = norm_contact(p, ind);
+    if (contact == -2) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
+    if ((size_t)nseg * n2 > c->seg_out_cap) {
+        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+        dev_free(c->d_seg_out); c->seg_out_cap = 0;
+        if ((rc = dev_alloc(&c->d_seg_out, (size_t)nseg * n2))) return rc;
+        c->seg_out_cap = (size_t)nseg * n2;
+    }
+    if ((rc = ensure_pinned(c, 2 * (size_t)m * sizeof(cplx) + nseg * n2 * sizeof(cplx) + (size_t)m * sizeof(int) + 64))) return rc;
+    if ((rc = gless_core(c, p, contact, m, c->d_E, c->d_w, c->d_seg_out, nseg, seg_end))) return rc;
     unsigned char* pout = c->h_pin + 2 * (size_t)m * sizeof(cplx);
     int* pinfo = reinterpret_cast<int*>(pout + nseg * n2 * sizeof(cplx));
     NEGF_HIP_CHECK(hipMemcpyAsync(pout, c->d_seg_out, nseg * n2 * sizeof(cplx), hipMemcpyDeviceToHost, c->stream));

@@ -18,8 +18,9 @@ import numpy as np
 from scipy.special import roots_legendre
 
 from .config import (TEMPERATURE, ADAPTIVE_INTEGRATION_TOL, N_KT, MAX_CYCLES, MAX_GRID_POINTS)
-from .integrate import GrInt, GrLessInt, GrIntSegments
+from .integrate import GrInt, GrLessInt, GrIntSegments, GrLessIntSegments
 
+_ENGINE_GRLESSINT = GrLessInt
 _ENGINE_GRINT = GrInt     # speculation over several levels only while GrInt is the engine's own: a rebound name
                           # (the bookkeeping spies, an oracle-served replay) sees the reference's call sequence
 
@@ -305,13 +306,20 @@ def densityGrid(F, S, g, mu1, mu2, ind=None, tol=ADAPTIVE_INTEGRATION_TOL, T=TEM
     muLo, muHi, dInt, Emin, Emax = _window(mu1, mu2, T)
     mid = (Emax - Emin) / 2
 
-    def computePoint(x, w):
+    def grid(x, w):
         E = mid * (x + 1) + Emin
         dFermi = fermi(E, muHi, T) - fermi(E, muLo, T)
-        weights = mid * w * dFermi * dInt
-        return GrLessInt(F, S, g, E, weights, ind)
+        return E, mid * w * dFermi * dInt
 
-    den = integratePointsAdaptiveANT(computePoint, tol=tol, debug=debug)
+    def computePoint(x, w):
+        return GrLessInt(F, S, g, *grid(x, w), ind)
+
+    def computeLevels(nodes):
+        return GrLessIntSegments(F, S, g, [grid(x, w) for x, w in nodes], ind)
+
+    den = integratePointsAdaptiveANT(computePoint, tol=tol, debug=debug,
+                                     computeLevels=computeLevels if GrLessInt is _ENGINE_GRLESSINT else None,
+                                     budget=_speculation_budget(F))
     if debug:
         print('Integration done!')
     return den / (2 * np.pi)

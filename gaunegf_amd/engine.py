@@ -275,6 +275,18 @@ class Engine:
         self._numerical(rc, info[:E.size], "gr_int_seg")
         return [out[k] for k in range(len(segments))]
 
+    def gless_int_seg(self, handle, ind, segments):
+        """[sum_m w_m G Gamma G^H for (E, w) in segments] from ONE pass over all the energies (negf_gless_int_seg)."""
+        Es = [np.asarray(E).ravel() for E, _ in segments]
+        E, w = self._grid(np.concatenate(Es), np.concatenate([np.asarray(w).ravel() for _, w in segments]))
+        ends = np.ascontiguousarray(np.cumsum([e.size for e in Es]), dtype=np.int32)
+        out = np.zeros((len(segments), self.n, self.n), dtype=np.complex128)
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_gless_int_seg(self._ctx, handle, _ind(ind), E.size, _ptr(E), _ptr(w), len(segments),
+                                                _ptr(ends), _ptr(out), _ptr(info)), "negf_gless_int_seg")
+        self._numerical(rc, info[:E.size], "gless_int_seg")
+        return [out[k] for k in range(len(segments))]
+
     def gless_int(self, handle, ind, E, w):
         E, w = self._grid(E, w)
         out = np.zeros((self.n, self.n), dtype=np.complex128)

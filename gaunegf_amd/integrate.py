@@ -206,6 +206,21 @@ def GrIntSegments(F, S, g, segments):
     return engine.gr_int_seg(g._negf_lower(engine), segs)
 
 
+def GrLessIntSegments(F, S, g, segments, ind=None):
+    """``[GrLessInt(F, S, g, E, w, ind) for (E, w) in segments]`` from one pass of the engine (negf_gless_int_seg); a plain
+    loop under the same conditions as GrIntSegments."""
+    F = np.asarray(F)
+    S = np.asarray(S)
+    segs = [(np.asarray(E), np.asarray(w)) for E, w in segments]
+    for E, w in segs:
+        _check(F, S, E, w)
+    if not hasattr(g, "_negf_lower") or _dist.is_active() or _split_depth or _spin_split(F, S, g) is not None or len(segs) < 2:
+        return [GrLessInt(F, S, g, E, w, ind) for E, w in segs]
+    engine = get_engine()
+    engine.set_system(F, S)
+    return engine.gless_int_seg(g._negf_lower(engine), ind, segs)
+
+
 def GrLessInt(F, S, g, Elist, weights, ind=None):
     """Integrated lesser Green's function, N x N complex (integrate.py:177-208).
     ``ind`` is None (total Sigma) or a contact index (0, -1, ...)."""

@@ -160,6 +160,10 @@ int negf_gr_int(negf_ctx* ctx, int handle, int m, const double* E_c128,
 int negf_gr_int_seg(negf_ctx* ctx, int handle, int m, const double* E_c128, const double* w_c128,
                     int nseg, const int* seg_end, double* out_c128, int* info);
 
+/* ... and the same for GrLessInt: the levels of the adaptive bias-window integral (densityGrid, density.py:605-658). */
+int negf_gless_int_seg(negf_ctx* ctx, int handle, int ind, int m, const double* E_c128, const double* w_c128,
+                       int nseg, const int* seg_end, double* out_c128, int* info);
+
 /* sum_m w_m G Gamma_c G^H -- GrLessInt, integrate.py:177-208 (+ :74-82). */
 int negf_gless_int(negf_ctx* ctx, int handle, int ind, int m, const double* E_c128,
                    const double* w_c128, double* out_c128, int* info);

@@ -248,3 +248,59 @@ def test_tile_layout_kernel_in_a_fresh_process():
     env = dict(os.environ, NEGF_SMALL_KERNEL="tile")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_segments_across_workspace_chunks(engine):
+    """The kernel-sequence path of negf_gr_int_seg streams the energies through the workspace in chunks: segments that
+    straddle chunk boundaries (a workspace of 5 energies, segments of 2, 4, 12 and 7 points) still sum correctly."""
+    from gaunegf_amd.integrate import GrInt, GrIntSegments
+    F, S, g, _ = _const(130, 77)
+    rng = np.random.default_rng(5)
+    segs = [(rng.uniform(-2, 2, k) + 0.05j, rng.standard_normal(k) + 0j) for k in (2, 4, 12, 7)]
+    ref = [GrInt(F, S, g, E, w) for E, w in segs]
+    engine.set_batch(5)
+    try:
+        got = GrIntSegments(F, S, g, segs)
+    finally:
+        engine.set_batch(0)
+    for a, b in zip(got, ref):
+        assert rel_fro(a, b) < 1e-12
+
+
+@pytest.mark.parametrize("N", [24, 60, 130])
+def test_segmented_lesser_integrals_and_adaptive_bias_window(engine, N, capsys):
+    """negf_gless_int_seg: every segment's G Gamma G^H sum equals GrLessInt on that segment alone (ind = None, 0, -1;
+    through the compact and the dense coupling products, a workspace smaller than the grid); densityGrid with its levels
+    evaluated together equals level by level and the oracle-served run."""
+    from gaunegf_amd import density as D
+    from gaunegf_amd.integrate import GrLessInt, GrLessIntSegments
+    F, S, g, g_ref = _const(N, 200 + N)
+    rng = np.random.default_rng(N)
+    segs = [(rng.uniform(-1, 1, k) + 0j, rng.standard_normal(k) + 0j) for k in (2, 4, 12, 5)]
+    for ind in (None, 0, -1):
+        got = GrLessIntSegments(F, S, g, segs, ind)
+        for (E, w), a in zip(segs, got):
+            assert rel_fro(a, GrLessInt(F, S, g, E, w, ind)) < 1e-12, ind
+        assert rel_fro(got[2], oracle.GrLessInt(F, S, g_ref, *segs[2], ind)) < TOL
+    engine.set_gamma_algo(1); engine.set_batch(7)
+    try:
+        dense = GrLessIntSegments(F, S, g, segs, -1)
+    finally:
+        engine.set_gamma_algo(0); engine.set_batch(0)
+    for a, (E, w) in zip(dense, segs):
+        assert rel_fro(a, GrLessInt(F, S, g, E, w, -1)) < 1e-12
+    spec = D.densityGrid(F, S, g, 0.25, -0.25, ind=-1, tol=1e-7, T=300.0)
+    old = D.SPECULATIVE_POINTS
+    D.SPECULATIVE_POINTS = 0
+    try:
+        plain = D.densityGrid(F, S, g, 0.25, -0.25, ind=-1, tol=1e-7, T=300.0)
+    finally:
+        D.SPECULATIVE_POINTS = old
+    assert rel_fro(spec, plain) < 1e-12
+    saved = D.GrLessInt
+    D.GrLessInt = oracle.GrLessInt
+    try:
+        ref = D.densityGrid(F, S, g_ref, 0.25, -0.25, ind=-1, tol=1e-7, T=300.0)
+    finally:
+        D.GrLessInt = saved
+    assert rel_fro(spec, ref) < TOL
