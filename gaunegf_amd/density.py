@@ -97,6 +97,42 @@ def _ant_levels(maxN):
     return out
 
 
+def _adaptive_ant_steps(levels, tol, budget, direct=None):
+    """The refinement itself, as a generator: yields the list of level indices it wants evaluated next (the level it
+    needs and, while they fit ``budget`` nodes, the ones after it), receives ``{index: value}``, and returns the integral
+    -- the update and the stopping test of density.py:239-268, level by level, whoever evaluates the nodes and in
+    whatever company.  ``direct(N)`` (debug only) evaluates the whole level-N rule for the reference's debug prints."""
+    ahead = {}
+    P = new_P = None
+    N = 2
+    maxDP = 1e10
+    for i, (N, x_new, w_new, ratio) in enumerate(levels):
+        if i not in ahead:
+            group, pts = [], 0
+            for j in range(i, len(levels)):
+                if group and pts + levels[j][1].size > budget:
+                    break
+                group.append(j); pts += levels[j][1].size
+            ahead.update((yield group))
+        if ratio is None:
+            P = ahead.pop(i)
+        else:
+            new_P = P * ratio
+            new_P += ahead.pop(i)
+            maxDP = np.max(np.abs(new_P - P))
+            if direct is not None:
+                full = direct(N)
+                print(f"N={N}, nested-weight ratio ~ {ratio:.3f}, maxDP={maxDP:.3e}")
+                print(f"Direct Calculation: N={N}, maxDP={np.max(np.abs(full - P)):.3e}, "
+                      f"maxDiff={np.max(np.abs(full - new_P)):.3e}")
+            P = new_P.copy()
+            if maxDP < tol:
+                print(f'Adaptive integration converged to {maxDP:.3e} in {N} points.')
+                return new_P
+    print(f'Adaptive integration reached full grid ({N / 1} points), final error {maxDP:.3e}')
+    return new_P
+
+
 def integratePointsAdaptiveANT(computePoint, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, debug=False,
                                computeLevels=None, budget=None):
     """Adaptive nested quadrature (density.py:211-273): levels N = 2, 6, 18, ...; each
@@ -109,46 +145,50 @@ def integratePointsAdaptiveANT(computePoint, tol=ADAPTIVE_INTEGRATION_TOL, maxN=
     what a launch of 54 does -- and consumed level by level with the reference's own update and stopping test; values
     computed past the level that converges are dropped."""
     levels = _ant_levels(maxN)
-    ahead = {}                                          # level index -> value, evaluated ahead of its turn
     if budget is None:
         budget = SPECULATIVE_POINTS
-
-    def value_of(i):
-        if i not in ahead:
-            group, pts = [], 0
-            for j in range(i, len(levels)):
-                if group and (computeLevels is None or debug or pts + levels[j][1].size > budget):
-                    break
-                group.append(j); pts += levels[j][1].size
-            if len(group) == 1:
-                ahead[i] = computePoint(levels[i][1], levels[i][2])
+    if computeLevels is None or debug:
+        budget = 0                                      # level by level: the reference's call sequence
+    steps = _adaptive_ant_steps(levels, tol, budget,
+                                (lambda N: computePoint(*getANTPoints(N))) if debug else None)
+    try:
+        want = next(steps)
+        while True:
+            if len(want) == 1:
+                got = {want[0]: computePoint(levels[want[0]][1], levels[want[0]][2])}
             else:
-                for j, v in zip(group, computeLevels([(levels[j][1], levels[j][2]) for j in group])):
-                    ahead[j] = v
-        return ahead.pop(i)
+                got = dict(zip(want, computeLevels([(levels[j][1], levels[j][2]) for j in want])))
+            want = steps.send(got)
+    except StopIteration as done:
+        return done.value
 
-    P = new_P = None
-    N = 2
-    maxDP = 1e10
-    for i, (N, x_new, w_new, ratio) in enumerate(levels):
-        if ratio is None:
-            P = value_of(i)
-        else:
-            new_P = P * ratio
-            new_P += value_of(i)
-            maxDP = np.max(np.abs(new_P - P))
-            if debug:
-                x, w = getANTPoints(N)
-                direct = computePoint(x, w)
-                print(f"N={N}, nested-weight ratio ~ {ratio:.3f}, maxDP={maxDP:.3e}")
-                print(f"Direct Calculation: N={N}, maxDP={np.max(np.abs(direct - P)):.3e}, "
-                      f"maxDiff={np.max(np.abs(direct - new_P)):.3e}")
-            P = new_P.copy()
-            if maxDP < tol:
-                print(f'Adaptive integration converged to {maxDP:.3e} in {N} points.')
-                return new_P
-    print(f'Adaptive integration reached full grid ({N / 1} points), final error {maxDP:.3e}')
-    return new_P
+
+def integrateJointlyAdaptiveANT(node_grids, computeSegments, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, budget=None):
+    """Several adaptive integrations of ONE system advanced together: ``node_grids[k](x, w) -> (energies, weights)`` maps
+    the rule's nodes to integral k's grid, ``computeSegments([(E, w), ...]) -> [value, ...]`` evaluates any list of grids
+    in one pass.  In every round each integration that is still refining asks for its next levels, all requests go out
+    as ONE call, and each integration consumes its own values with its own stopping test -- the contour and the
+    Fermi-tail integral of densityComplex share their launches that way.  Returns the list of integrals."""
+    levels = _ant_levels(maxN)
+    if budget is None:
+        budget = SPECULATIVE_POINTS
+    runs = [_adaptive_ant_steps(levels, tol, budget) for _ in node_grids]
+    want, result = {}, [None] * len(runs)
+    for k, r in enumerate(runs):
+        want[k] = next(r)
+    while want:
+        owners = [(k, j) for k in sorted(want) for j in want[k]]
+        values = computeSegments([node_grids[k](levels[j][1], levels[j][2]) for k, j in owners])
+        got = {k: {} for k in want}
+        for (k, j), v in zip(owners, values):
+            got[k][j] = v
+        for k in sorted(got):
+            try:
+                want[k] = runs[k].send(got[k])
+            except StopIteration as done:
+                result[k] = done.value
+                del want[k]
+    return result
 
 
 # ------------------------------------------------------------ grid builders
@@ -357,20 +397,27 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
     def on_tail(x, w):
         return half_width * (x) + mu, half_width * w
 
-    def integral_over(node_map):
+    def grid_of(node_map):
         def grid(x, w):
             z, wz = node_map(x, w)
             return z, wz * fermi(z, mu, T)
+        return grid
 
-        def level(x, w):
-            return GrInt(F, S, g, *grid(x, w))
-
-        def levels(nodes):
-            return GrIntSegments(F, S, g, [grid(x, w) for x, w in nodes])
-        return integratePointsAdaptiveANT(level, tol=tol, debug=debug,
-                                          computeLevels=levels if GrInt is _ENGINE_GRINT else None,
+    def integral_over(node_map):
+        grid = grid_of(node_map)
+        return integratePointsAdaptiveANT(lambda x, w: GrInt(F, S, g, *grid(x, w)), tol=tol, debug=debug,
+                                          computeLevels=(lambda nodes: GrIntSegments(F, S, g, [grid(x, w) for x, w in nodes]))
+                                          if GrInt is _ENGINE_GRINT else None,
                                           budget=_speculation_budget(F))
 
+    if T > 0 and GrInt is _ENGINE_GRINT and not debug and _speculation_budget(F) > 0:
+        # the contour and the Fermi tail refine together: one launch per round for both (integrateJointlyAdaptiveANT)
+        print('Complex Contour Integration (with the Fermi broadening):')
+        total, tail = integrateJointlyAdaptiveANT([grid_of(on_arc), grid_of(on_tail)],
+                                                  lambda segs: GrIntSegments(F, S, g, segs), tol=tol,
+                                                  budget=_speculation_budget(F))
+        total += tail
+        return (1 + 0j) * np.imag(total) / np.pi
     print('Complex Contour Integration:')
     total = integral_over(on_arc)
     if T > 0:
