@@ -1516,7 +1516,10 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     // kernels fill the chip by themselves and the groups mostly run in lockstep: + 2 % (1000 x N = 500 33.1 -> 33.8 TF).
     static int split_max = -1;
     if (split_max < 0) { const char* e = getenv("NEGF_GJ_SPLIT_MAX"); split_max = e ? atoi(e) : 1 << 30; }
-    const int groups = (nb <= split_max && !d_stamps) ? std::max(1, std::min(4, nb / 12)) : 1;
+    static int grp_max = -1, grp_min = -1;          // NEGF_GJ_GROUP_MAX (<= GjSideStreams::MAXG), NEGF_GJ_GROUP_MIN: matrices per group
+    if (grp_max < 0) { const char* e = getenv("NEGF_GJ_GROUP_MAX"); grp_max = e ? std::min(std::max(atoi(e), 1), (int)GjSideStreams::MAXG) : 4; }
+    if (grp_min < 0) { const char* e = getenv("NEGF_GJ_GROUP_MIN"); grp_min = e ? std::max(atoi(e), 1) : 12; }
+    const int groups = (nb <= split_max && !d_stamps) ? std::max(1, std::min(grp_max, nb / grp_min)) : 1;
     if (groups == 1) {
         chain(st, 0, nb);
     } else {
