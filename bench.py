@@ -516,7 +516,9 @@ def worker_c3(args):
             line["extra"] = {"north_star_N500_x_1000": extra_const(eng, 500, 50, 1000, 3, reps=3, cpu_budget=6.0,
                                                                    no_cpu=args.no_cpu, whole_host=not args.no_whole_host),
                              "C2_N200_x_1000": extra_const(eng, 200, 20, 1000, 2, reps=10, cpu_budget=4.0,
-                                                           no_cpu=args.no_cpu)}
+                                                           no_cpu=args.no_cpu),
+                             # BASELINE configs[0]-sized: 60 basis functions (the ethane demo), 100 real-axis points
+                             "C1_N60_x_100": extra_const(eng, 60, 6, 100, 1, reps=20, cpu_budget=2.0, no_cpu=args.no_cpu)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -833,9 +835,15 @@ def extra_const(eng, N, nc, M, seed, reps, cpu_budget, no_cpu, whole_host=False)
     dt = (time.perf_counter() - t0) / reps
     inv_ms, inv_l = eng.profile_read("inverse")
     fl = eng.profile_read_flops("inverse")
+    small_ms, small_l = eng.profile_read("small")
     eng.profile(False)
-    res = {"n_orb": N, "energies": M, "gpu_ms_per_density_matrix": dt * 1e3, "gpu_points_per_s": M / dt,
-           "inverse_ms_per_pass": inv_ms / reps, "inverse_roofline": roofline_pair(fl[0], fl[1], inv_ms * 1e-3)}
+    res = {"n_orb": N, "energies": M, "gpu_ms_per_density_matrix": dt * 1e3, "gpu_points_per_s": M / dt}
+    if inv_l:
+        res.update({"inverse_ms_per_pass": inv_ms / reps, "inverse_roofline": roofline_pair(fl[0], fl[1], inv_ms * 1e-3)})
+    if small_l:
+        # n <= 96: assemble + inverse + weighted sum in one kernel on the vector units (no matrix cores): latency-bound
+        res.update({"single_kernel_ms_per_pass": small_ms / reps,
+                    "single_kernel_gflops_algorithmic": 8.0 * N ** 3 * M * reps / (small_ms * 1e-3) / 1e9})
     if not no_cpu:
         import oracle
         g = oracle.ConstSigma(F, S, inds, -0.1j)

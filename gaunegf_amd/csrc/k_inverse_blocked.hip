@@ -342,7 +342,7 @@ __global__ __launch_bounds__(C::THREADS) void gj_blocked_kernel(
                stamps of workgroup 0, [step+1][8]; nullptr in production */)
 {
     constexpr int NB = C::NB, RPT = C::RPT, PW = C::PW;
-    constexpr int GJB_THREADS = C::THREADS, GJB_WAVES = C::NW, PT = C::PT;
+    constexpr int GJB_THREADS = C::THREADS, GJB_WAVES = C::NW;
     constexpr int S = C::S, TPR = C::TPR;
     constexpr int KS = NB / 4;                     // MFMA k-steps per tile
 
@@ -380,7 +380,6 @@ __global__ __launch_bounds__(C::THREADS) void gj_blocked_kernel(
     }
     __syncthreads();
 
-    const int fi = lane & 15, fk = lane >> 4;
     const int tiles = rows16 >> 4;
     auto stamp = [&](int step, int slot, int w) __attribute__((always_inline)) {
         if (stamps && blockIdx.x == 0 && wave == w && lane == 0)
@@ -1430,7 +1429,6 @@ __global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __re
 template <int NBI, int RPT>
 void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp)
 {
-    using C = GjCfg<NBI, 1, RPT, PW, PW>;
     const size_t smem = (size_t)(2 * PW * NBI + 2 * NBI * WIN) * sizeof(cplx);      // candidate rows + Q of two sub-panels
     auto kern = gj_window_kernel<NBI, RPT>;
     static bool attr_set = false;
