@@ -71,6 +71,7 @@ SIGNATURES = {
     "negf_set_inverse_algo": (C.c_int, [_vp, C.c_int]),
     "negf_set_gamma_algo": (C.c_int, [_vp, C.c_int]),
     "negf_set_small_algo": (C.c_int, [_vp, C.c_int]),
+    "negf_set_chain_round_robin": (C.c_int, [_vp, C.c_int, C.c_int]),
     "negf_selftest_mfma": (C.c_int, [_vp, _dp]),
 }
 

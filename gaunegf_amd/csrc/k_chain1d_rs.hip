@@ -56,6 +56,9 @@ constexpr int RS_NB = RS_PANEL;           // panel width of the small inverse: h
                                       // (1: built and measured in round 4 -- parity green, the C3 launch 666 ms against 668: with
                                       // three workgroups per CU a barrier's wait is another workgroup's issue slot, not idle time)
 #endif
+#ifndef RS_RR
+#define RS_RR 1
+#endif
 #ifndef RS_STAMPS
 #define RS_STAMPS 0                   // 1: diagnostic build -- the phase / cycle stamps of NEGF_CHAIN_STAMPS=1 are compiled in
 #endif                                //    (NEGF_EXTRA_HIPCC_FLAGS=-DRS_STAMPS=1 python -m gaunegf_amd.build --force); the production
@@ -79,7 +82,59 @@ struct ChainRsArgs {
     unsigned long long* stamps;      // diagnostic (RS_STAMPS build + NEGF_CHAIN_STAMPS): wall-clock stamps of workgroup (0,0), 10th sweep
     int stamp_sweep;                 // diagnostic: the sweep of job 0 whose phases are stamped (NEGF_CHAIN_STAMP_SWEEP, default 10)
     int simd_roles;                  // 1: wave roles follow the SIMD a wave runs on (see rs_wave_role), 0: the wave number
+    // round-robin execution (rr_quantum > 0): the launch is one PERSISTENT workgroup per resident slot; the jobs wait
+    // in a FIFO queue (entries 0 .. rr_jobs-1: the launch order, then rr_ring), a workgroup runs a job for rr_quantum
+    // sweeps and -- if other jobs are waiting -- leaves the iterate in the job's (still unused) output block, puts the
+    // job at the back of the queue and takes the one at the front.  Jobs of unknown length then finish in order of
+    // their length and the chip stays full until fewer jobs than slots are left, whatever the launch order was.
+    int rr_quantum;
+    struct RsQueue* rr_q;            // (in device memory: its fields are only needed when a job starts or is set aside)
 };
+struct RsQueue {
+    unsigned head, tail;             // next entry to pop / to push
+    unsigned jobs, cap;              // jobs of the launch (entries 0 .. jobs-1 of the queue), entries of the ring
+    unsigned long long ring[];       // (sweep count << 32) | job; ~0 = not written yet
+};
+
+// front of the job queue (lane 0 of a workgroup): (count << 32) | job, or -1 when the queue is empty.  An empty queue
+// stays empty: a job is only ever pushed by a workgroup that saw other jobs waiting, so a workgroup that finds it
+// empty is done (every job is then held by a running workgroup, which finishes it itself).
+__device__ __forceinline__ long long rs_rr_pop(RsQueue* q, const int* order)
+{
+    const unsigned jobs = q->jobs;
+    for (;;) {
+        const unsigned h = __hip_atomic_load(&q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_load(&q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h >= t) return -1;
+        unsigned expect = h;
+        if (!__hip_atomic_compare_exchange_strong(&q->head, &expect, h + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            continue;
+        if (h < jobs) return order ? order[h] : (int)h;
+        // (the pusher reserved this entry before writing it: it is a running workgroup between two instructions)
+        unsigned long long v;
+        do { v = __hip_atomic_load(&q->ring[h - jobs], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (v == ~0ull);
+        return (long long)v;
+    }
+}
+// are other jobs waiting (and is there room to queue this one)?
+__device__ __forceinline__ bool rs_rr_waiting(RsQueue* q)
+{
+    const unsigned h = __hip_atomic_load(&q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_load(&q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return h < t && t - q->jobs + 1024u < q->cap;
+}
+__device__ __forceinline__ void rs_rr_push(RsQueue* q, int job, int count)
+{
+    const unsigned t = __hip_atomic_fetch_add(&q->tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&q->ring[t - q->jobs], ((unsigned long long)(unsigned)count << 32) | (unsigned)job,
+                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void rs_rr_init_kernel(RsQueue* q, unsigned cap, unsigned jobs)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) q->ring[i] = ~0ull;
+    if (i == 0) { q->head = 0u; q->tail = jobs; q->jobs = jobs; q->cap = cap; }
+}
 
 // maximum of a 32-bit key over the wave (all lanes active), wave-uniform result.  Four DPP steps inside the rows
 // of 16 lanes leave the row maximum in every lane of a row; row_bcast:15 / row_bcast:31 (the GFX9 wave-reduction
@@ -546,12 +601,11 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
 
     // job of this launch slot: in launch order, or -- when the provider has seen this grid before -- in
     // the order of decreasing sweep counts of the previous evaluation (the jobs differ by up to 20x in
-    // length; started longest first, the last workgroups of the grid do not leave the chip idle)
+    // length; started longest first, the last workgroups of the grid do not leave the chip idle).
+    // Round robin (a.rr_quantum > 0): the slot is a persistent workgroup and takes its jobs from the queue.
     const int slot = blockIdx.y * gridDim.x + blockIdx.x;
-    const int job = a.order ? a.order[slot] : slot;
-    const int c = job % a.n_contacts, b = job / a.n_contacts;
-    const int n = a.nc[c];
-    const int off = a.blk_off[c];
+    const bool rr = RS_RR && a.rr_quantum > 0;
+    __shared__ long long rr_msg;
     cplx* Ws = reinterpret_cast<cplx*>(smem_raw);       // [16*T16][P] (+ slack): g (start of a sweep), T, M, the reduced M
     const int tid = threadIdx.x, lane = tid & 63;
     // ---- wave roles.  A v_mfma_f64_16x16x4 holds its SIMD's vector issue for ~45 of its 64 cycles whatever the
@@ -579,8 +633,10 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         wave = __builtin_amdgcn_readfirstlane(wave);
         __syncthreads();
     }
+    // ---- the job: set by next_job() below -- once, or (round robin) whenever this workgroup takes another one
+    int job = 0, count = 0, c = 0, b = 0, n = 1, off = 0, ksteps = 1;
+    bool resume = false;                                // a job that was set aside after `count` sweeps: its iterate waits in blk
     const int fi = lane & 15, fk = lane >> 4;
-    const int ksteps = (n + 3) >> 2;
     // the old iterate, element (ks*4 + fk, wave*16 + fi) of g at slot ks of this lane
     // (global: [slot][thread], coalesced; LDS: a compact n x n matrix behind the work matrix)
     // Slot ks < gold_lds_slots: LDS, a compact matrix (pitch n) at element gold_lds_off of the dynamic LDS --
@@ -589,17 +645,14 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // finite values.  The other slots: global scratch [slot][thread] (coalesced); with the LDS part taken
     // off, the scratch of the workgroups of an XCD fits its 4 MB L2 and is rewritten there sweep after sweep.
     cplx* gold_g = GOLD_GLOBAL ? a.gold + ((size_t)slot * KS) * RS_THREADS + tid : nullptr;
-    cplx* gold_l = Ws + a.gold_lds_off + fk * n + wave * 16 + fi;
+    cplx* gold_l = Ws;
     // LDS slots of the old iterate: LS_CT (what fits when n = P, a compile-time number) or one more
     constexpr int LS_FIT = (16 * T16 * P + 16 - (P + 2) * P) / (4 * P);
     constexpr int LS_CT = GOLD_GLOBAL ? (LS_FIT > 0 ? LS_FIT : 0) : KS;
     const int lds_slots = GOLD_GLOBAL ? a.gold_lds_slots : KS;
 
-    const cplx* alpha = a.alpha + off; const cplx* Salpha = a.Salpha + off;
-    const cplx* beta = a.beta + off;   const cplx* Sbeta = a.Sbeta + off;
-    const cplx* tau = a.tau + off;     const cplx* Stau = a.Stau + off;
-    const cplx e = E[b];
-    const cplx z = cmake(e.x, e.y + a.eta);
+    const cplx *alpha = a.alpha, *Salpha = a.Salpha, *beta = a.beta, *Sbeta = a.Sbeta, *tau = a.tau, *Stau = a.Stau;
+    cplx e = cmake(0.0, 0.0), z = e;
     const double conv2 = a.conv * a.conv, rf = a.relFactor, rf1 = 1.0 - a.relFactor;
     auto sel = [](bool ok, cplx v) { return cmake(ok ? v.x : 0.0, ok ? v.y : 0.0); };
     // A = (E + i eta) Sa - a at (i, j); global loads at clamped (always valid) indices
@@ -617,7 +670,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
 #define RS_PF 1
 #endif
     constexpr int PF = RS_PF;                       // k-steps the streamed operand is requested ahead
-    const cplx* opS = Sbeta; const cplx* opM = beta; cplx opz = z;
+    const cplx* opS = Sbeta; const cplx* opM = beta; cplx opz = z;     // (set per job and per pass)
     struct Stream { cplx s[PF], m[PF]; };
     auto stream_fetch = [&](Stream& q, const cplx* sS, const cplx* sM, int ks, int fk) __attribute__((always_inline)) {
         const int kc = min(ks * 4 + fk, n - 1);
@@ -816,34 +869,81 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         __syncthreads();
     };
 
-    // ---- g0 = inv(A); the padding of the work matrix is zeroed once and never written again
-    // (a cache hit starts from the stored iterate instead and goes straight to Sigma = t g t^H)
+    // ---- a job starts: g0 = inv(A) is the first pass through the inverse of a fresh job, so the work matrix starts as A
+    // (its padding zero; it is never written afterwards).  A cache hit starts from the stored iterate instead and goes
+    // straight to Sigma = t g t^H; a job that was set aside continues from its iterate with the products of its next sweep.
     const bool gc_hit = a.gc_mode == 2;
-    if (gc_hit) {
-        const cplx* gcj = a.gcache + (size_t)b * a.blk_stride + off;
-        for (int t = tid; t < WELEMS; t += RS_THREADS) {
-            const int i = t / P, j = t - i * P;
-            Ws[t] = sel(i < n && j < n, gcj[min(i, n - 1) * n + min(j, n - 1)]);
+    bool first = true, final_pass = false, skip = false;
+    int q_end = 0;
+    auto next_job = [&]() __attribute__((always_inline)) -> bool {
+        if (rr) {
+            if (tid == 0) rr_msg = rs_rr_pop(a.rr_q, a.order);
+            __syncthreads();                            // (also: every wave is done with the LDS of the previous job)
+            const long long ent = rr_msg;
+            __syncthreads();
+            if (ent < 0) return false;
+            job = (int)(ent & 0xffffffffll); count = (int)(ent >> 32);
+        } else {
+            job = a.order ? a.order[slot] : slot; count = 0;
         }
-    } else {
-        for (int t = tid; t < WELEMS; t += RS_THREADS) {
-            const int i = t / P, j = t - i * P;
-            Ws[t] = sel(i < n && j < n, Aat(i, j));
+        resume = count > 0;
+        c = job % a.n_contacts; b = job / a.n_contacts;
+        n = a.nc[c]; off = a.blk_off[c]; ksteps = (n + 3) >> 2;
+        gold_l = Ws + a.gold_lds_off + fk * n + wave * 16 + fi;
+        alpha = a.alpha + off; Salpha = a.Salpha + off; beta = a.beta + off; Sbeta = a.Sbeta + off;
+        tau = a.tau + off; Stau = a.Stau + off;
+        e = E[b]; z = cmake(e.x, e.y + a.eta);
+        opS = Sbeta; opM = beta; opz = z;
+        over = 1; allok = 0;
+        first = !resume; skip = resume; final_pass = false;
+        q_end = count + a.rr_quantum;
+        if (gc_hit || resume) {
+            if (resume) __threadfence();                // (acquire side of the queue entry lane 0 popped: the iterate below was
+                                                        //  written by another workgroup of this launch)
+            const cplx* gcj = (gc_hit ? a.gcache : blk) + (size_t)b * a.blk_stride + off;
+            for (int t = tid; t < WELEMS; t += RS_THREADS) {
+                const int i = t / P, j = t - i * P;
+                Ws[t] = sel(i < n && j < n, gcj[min(i, n - 1) * n + min(j, n - 1)]);
+            }
+        } else {
+            for (int t = tid; t < WELEMS; t += RS_THREADS) {
+                const int i = t / P, j = t - i * P;
+                Ws[t] = sel(i < n && j < n, Aat(i, j));
+            }
         }
-    }
-    if (tid < 64) { colof[tid] = -1; pivrow[tid] = 0; }
-    __syncthreads();
+        if (resume) {
+            // the old iterate of the mixing step is the iterate itself (gather_mix leaves the mixed g in both places)
+            __syncthreads();
+            const int fi = rs_opaque(lane & 15), fk = rs_opaque(lane >> 4);
+            const int col = wave * 16 + fi;
+            cplx* gl = rs_opaque(gold_l);
+            cplx* gg = GOLD_GLOBAL ? rs_opaque(gold_g) : nullptr;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks < ksteps && col < n && ks * 4 + fk < n) {
+                    const cplx v = Ws[(ks * 4 + fk) * P + col];
+                    if (!GOLD_GLOBAL || ks < LS_CT || (ks == LS_CT && lds_slots > LS_CT)) gl[ks * 4 * n] = v; else gg[ks * RS_THREADS] = v;
+                }
+            }
+        }
+        if (tid < 64) { colof[tid] = -1; pivrow[tid] = 0; }
+        __syncthreads();
+        return true;
+    };
 
     // One copy of every phase in the instruction stream (the loop body has to stay inside the 64 KB
     // instruction cache two CUs share): the start g0 = inv(A) is the first pass through the inverse, and
     // Sigma = t g t^H (t = E Stau - tau, no eta) runs as a last pass through the two products with t in
     // place of B:  X = t g (row tiles) -> Ws,  Sigma = X t^H (column tiles) -> global.
-    int count = 0;
-    bool first = true, final_pass = false;
+    bool need_job = true;
     while (true) {
+        if (need_job) {
+            if (!next_job()) break;                     // (round robin: the queue is empty -- every job is finished or held by a running workgroup)
+            need_job = false;
+        }
         unsigned long long* st = (RS_STAMPS && a.stamps && job == 0 && count == a.stamp_sweep) ? a.stamps : nullptr;
         if (st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
-        if (!gc_hit) {
+        if (!gc_hit && !skip) {
             rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, la_cnt, la_epoch, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
             if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
             gather_mix(first, st);
@@ -851,13 +951,33 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
             if (!first) ++count;
             first = false;
         }
-        if (gc_hit || (a.force_iters >= 0 ? count >= a.force_iters : !(over && count < a.max_iter))) {
+        if (skip) {
+            skip = false;
+        } else if (gc_hit || (a.force_iters >= 0 ? count >= a.force_iters : !(over && count < a.max_iter))) {
             final_pass = true;
             opS = Stau; opM = tau; opz = e;
             if (a.gc_mode == 1) {                       // a miss leaves its final iterate in the cache (g sits in Ws, complete
                 cplx* gcj = a.gcache + (size_t)b * a.blk_stride + off;                              //  since the barrier that ends gather_mix)
                 for (int t = tid; t < n * n; t += RS_THREADS) { const int i = t / n; gcj[t] = Ws[i * P + (t - i * n)]; }
             }
+        } else if (rr && count >= q_end) {
+            // the quantum is over.  Nobody waiting: carry on.  Otherwise the iterate goes to the job's output block (g sits in
+            // Ws, complete since the barrier that ends gather_mix), the job to the back of the queue, and this workgroup
+            // takes the job at the front
+            if (tid == 0) rr_msg = rs_rr_waiting(a.rr_q) ? 1 : 0;
+            __syncthreads();
+            const bool sw = rr_msg != 0;
+            __syncthreads();
+            if (sw) {
+                cplx* gsj = blk + (size_t)b * a.blk_stride + off;
+                for (int t = tid; t < n * n; t += RS_THREADS) { const int i = t / n; gsj[t] = Ws[i * P + (t - i * n)]; }
+                __threadfence();                        // release side: the iterate is visible before the queue entry is
+                __syncthreads();
+                if (tid == 0) rs_rr_push(a.rr_q, job, count);
+                need_job = true;
+                continue;
+            }
+            q_end = count + a.rr_quantum;
         }
         d4 mr[T16], mi[T16], mc[T16];
         // T = B g : row tile `wave`; g is read from Ws by every wave, so T waits in registers
@@ -875,7 +995,13 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
             for (int ti = 0; ti < T16; ++ti)
                 for_tile(ti, wave, mr[ti], mi[ti], mc[ti], true, fis, fks,
                          [&](int i, int j, double re, double im) { if (i < n && j < n) out[i * n + j] = cmake(re, im); });
-            break;
+            if (tid == 0 && !gc_hit) {                  // (a hit's counts and flags are copied from the cache by the launcher's caller)
+                if (iters) iters[(size_t)b * a.n_contacts + c] = count;
+                if (converged) converged[(size_t)b * a.n_contacts + c] = (count > 0 && allok) ? 1 : 0;
+            }
+            if (!rr) break;
+            need_job = true;
+            continue;
         }
         __syncthreads();
         // M = A - T B^H
@@ -890,26 +1016,47 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         __syncthreads();
         if (st && tid == 0) st[4] = __builtin_amdgcn_s_memrealtime();
     }
-    if (tid == 0 && !gc_hit) {                           // (a hit's counts and flags are copied from the cache by the launcher's caller)
-        if (iters) iters[(size_t)b * a.n_contacts + c] = count;
-        if (converged) converged[(size_t)b * a.n_contacts + c] = (count > 0 && allok) ? 1 : 0;
-    }
 }
 
 }  // namespace
 
 bool chain1d_lds_supported(int nc_max) { return nc_max <= 64; }
 
-size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb)
+namespace {
+// sweeps a job runs before it makes room for a waiting one (NEGF_CHAIN_RR, 0 = every job runs to its end in one go)
+int rs_rr_quantum(int user)
+{
+    if (user >= 0) return user;                      // negf_set_chain_round_robin
+    static int q = -1;
+    if (q < 0) { const char* e = getenv("NEGF_CHAIN_RR"); q = e ? std::max(atoi(e), 0) : 100; }
+    return q;
+}
+size_t rs_gold_elems(int nc_max, int n_contacts, int nb)
 {
     return (size_t)4 * ((nc_max + 15) >> 4) * RS_THREADS * n_contacts * nb;     // >= KS slots per lane
+}
+// entries of the job queue's ring: a job is queued at most once per quantum (0: no round robin for this launch)
+size_t rs_ring_entries(int n_contacts, int nb, int max_sweeps, int rr_user)
+{
+    const int q = rs_rr_quantum(rr_user);
+    if (q <= 0 || max_sweeps <= q) return 0;
+    const size_t jobs = (size_t)n_contacts * nb;
+    const size_t cap = jobs * ((size_t)max_sweeps / q + 1) + 2048;
+    return (cap >> 27) ? 0 : cap;
+}
+}  // namespace
+
+// lane-private copies of the iterate (one set per launch slot) + the job queue of the round-robin launch
+size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb, int max_sweeps, int rr_quantum)
+{
+    return rs_gold_elems(nc_max, n_contacts, nb) + 1 + (rs_ring_entries(n_contacts, nb, max_sweeps, rr_quantum) + 1) / 2;
 }
 
 namespace {
 
 template <int P>
 void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts, int nb, const cplx* E, cplx* blk,
-                       int* iters, int* conv, cplx* gold_scratch, int occ_env)
+                       int* iters, int* conv, cplx* gold_scratch, int occ_env, int rr_slots, unsigned rr_cap)
 {
     constexpr int T16 = (P - 1 + 15) / 16;
     const size_t wmat = (size_t)(16 * T16 * P + 16) * sizeof(cplx);
@@ -925,23 +1072,36 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
     constexpr int LS_FIT = (16 * T16 * P + 16 - (P + 2) * P) / (4 * P);      // the kernel's LS_CT
     ag.gold_lds_slots = std::min(std::max(0, (16 * T16 * P + 16 - ag.gold_lds_off) / (4 * n_max)), std::max(LS_FIT, 0) + 1);
     if (ag.gold_lds_slots < std::max(LS_FIT, 0)) ag.gold_lds_slots = 0;       // (cannot happen: n_max <= P)
-    auto launch = [&](auto kern, size_t smem) {
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    auto launch = [&](auto kern, size_t smem, int occ) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             (void)hipGetLastError();
-        hipLaunchKernelGGL(kern, dim3(n_contacts, nb), dim3(RS_THREADS), smem, st, smem > wmat ? al : ag, E, blk, iters, conv);
+        ChainRsArgs aa = smem > wmat ? al : ag;
+        dim3 grid(n_contacts, nb);
+        // round robin pays when jobs have to wait for a slot: one persistent workgroup per resident slot then
+        const int jobs = n_contacts * nb, slots = rr_slots > 0 ? std::min(rr_slots, occ * n_cus) : occ * n_cus;
+        if (aa.rr_quantum > 0 && jobs > slots) {
+            hipLaunchKernelGGL(rs_rr_init_kernel, dim3((rr_cap + 255) / 256), dim3(256), 0, st, aa.rr_q, rr_cap, (unsigned)jobs);
+            grid = dim3(slots, 1);
+        } else aa.rr_quantum = 0;
+        hipLaunchKernelGGL(kern, grid, dim3(RS_THREADS), smem, st, aa, E, blk, iters, conv);
     };
     constexpr int OCC_MAX = T16 <= 2 ? 4 : 3;          // register budget: 128 VGPRs (T16 <= 2), 168 above
-    if (occ_env != 2 && fits(wmat + gold_lds, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, false>, wmat + gold_lds);
-    else if (occ_env != 2 && gold_scratch && fits(wmat, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, true>, wmat);
-    else if (fits(wmat + gold_lds, 2) || !gold_scratch) launch(chain1d_rs_kernel<P, 2, false>, wmat + gold_lds);
-    else launch(chain1d_rs_kernel<P, 2, true>, wmat);
+    if (occ_env != 2 && fits(wmat + gold_lds, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, false>, wmat + gold_lds, OCC_MAX);
+    else if (occ_env != 2 && gold_scratch && fits(wmat, OCC_MAX)) launch(chain1d_rs_kernel<P, OCC_MAX, true>, wmat, OCC_MAX);
+    else if (fits(wmat + gold_lds, 2) || !gold_scratch) launch(chain1d_rs_kernel<P, 2, false>, wmat + gold_lds, 2);
+    else launch(chain1d_rs_kernel<P, 2, true>, wmat, 2);
 }
 
 }  // namespace
 
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
                         const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
-                        cplx* gcache, int gc_mode)
+                        cplx* gcache, int gc_mode, int rr_quantum, int rr_slots)
 {
     ChainRsArgs a;
     a.order = order;
@@ -953,6 +1113,16 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
     a.eta = p.eta; a.conv = p.conv; a.relFactor = p.relFactor;
     a.max_iter = p.max_iter; a.force_iters = p.force_iters;
     a.gold = gold_scratch;
+    // the job queue sits behind the iterate copies (chain1d_lds_scratch_elems); a cache hit runs no sweeps
+    a.rr_quantum = 0; a.rr_q = nullptr;
+    unsigned rr_cap = 0;
+    {
+        const size_t cap = rs_ring_entries(p.n_contacts, nb, std::max(p.max_iter, p.force_iters), rr_quantum);
+        if (gold_scratch && cap && a.gc_mode != 2) {
+            a.rr_q = reinterpret_cast<RsQueue*>(gold_scratch + rs_gold_elems(p.nc_max, p.n_contacts, nb));
+            rr_cap = (unsigned)cap; a.rr_quantum = rs_rr_quantum(rr_quantum);
+        }
+    }
     static unsigned long long* d_stamps = nullptr;
     static int want_stamps = -1;
     if (want_stamps < 0) {
@@ -981,7 +1151,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
         const int strip_base = n <= 16 ? -1 : n <= 19 ? 16 : (n > 32 && n <= 35) ? 32 : (n > 48 && n <= 51) ? 48 : -1;
         if (strip_base > 0 && n_min <= strip_base) n = strip_base == 16 ? 25 : strip_base == 32 ? 41 : 57;
     }
-#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n_max, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env)
+#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n_max, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env, rr_slots, rr_cap)
 #ifdef RS_FAST_BUILD
     if (n <= 16) RS_CASE(17); else RS_CASE(51);
 #else

@@ -89,7 +89,7 @@ void free_provider(SigmaProvider* p)
     dev_free(p->d_tau); dev_free(p->d_Stau);
     dev_free(p->d_atom_orbs); dev_free(p->d_nb_off); dev_free(p->d_nb_dirs);
     dev_free(p->d_H); dev_free(p->d_Slist); dev_free(p->d_Vlist); dev_free(p->d_xi);
-    dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order); dev_free(p->d_prevE); dev_free(p->d_prev_iters);
+    dev_free(p->d_pre_tot); dev_free(p->d_pre_c); dev_free(p->d_order); dev_free(p->d_prevE); dev_free(p->d_prev_iters); dev_free(p->d_curE); dev_free(p->d_cur_iters);
     delete p;
 }
 
@@ -394,7 +394,8 @@ int run_inverse(negf_ctx* c, int nb, int* info)
 }
 
 // Sigma blocks of a block provider for energies E[0..nb) -> c->d_blk
-int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* iters, int* conv)
+// (m0 = position of this chunk in the grid being evaluated: the sweep-count prediction keeps whole evaluations)
+int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* iters, int* conv, int m0)
 {
     if (p->kind == SK_CHAIN1D) {
         static int force_v1 = -1;
@@ -409,7 +410,7 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
         }
         ProfScope ps(c, hit ? "chain1d_hit" : "chain1d");
         if (lds_path) {
-            const size_t need = chain1d_lds_scratch_elems(p->nc_max, p->n_contacts, nb);
+            const size_t need = chain1d_lds_scratch_elems(p->nc_max, p->n_contacts, nb, std::max(p->max_iter, p->force_iters), c->chain_rr_quantum);
             if (need > c->scratch_cap) {
                 NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
                 dev_free(c->d_scratch); c->scratch_cap = 0;
@@ -439,31 +440,47 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                     if (rc) return rc;
                     p->order_cap = jobs;
                 }
+                if (m0 == 0 && p->cur_n > 0) {
+                    // a new evaluation begins: the one recorded so far becomes the reference
+                    std::swap(p->d_prevE, p->d_curE); std::swap(p->d_prev_iters, p->d_cur_iters);
+                    std::swap(p->prev_cap, p->cur_cap);
+                    p->prev_n = p->cur_n; p->cur_n = 0;
+                }
                 if (p->prev_n > 0) {
                     launch_chain1d_predict_order(c->stream, p->d_prevE, p->d_prev_iters, p->prev_n, p->n_contacts, E, nb, p->d_order);
+                    order = p->d_order;
+                } else if (p->cur_n > 0) {
+                    // the first evaluation ever, arriving in chunks: the chunks so far are all there is to learn from
+                    launch_chain1d_predict_order(c->stream, p->d_curE, p->d_cur_iters, p->cur_n, p->n_contacts, E, nb, p->d_order);
                     order = p->d_order;
                 }
             }
             launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, order,
-                               ent ? ent->d_g : nullptr, 1);
+                               ent ? ent->d_g : nullptr, 1, c->chain_rr_quantum, c->chain_rr_slots);
             if (ent) {
                 NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_it, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
                 NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_cv, conv, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
                 ent->valid = true;
             }
-            if (can_order) {
-                // keep this evaluation's energies and counts for the next prediction
-                if (nb > p->prev_cap) {
-                    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
-                    dev_free(p->d_prevE); dev_free(p->d_prev_iters); p->prev_cap = 0; p->prev_n = 0;
+            if (can_order && (m0 == 0 || m0 == p->cur_n)) {
+                // append this chunk's energies and counts to the record of the evaluation in progress
+                if (m0 == 0) p->cur_n = 0;
+                if (m0 + nb > p->cur_cap) {
+                    const int cap = std::max(m0 + nb, 2 * p->cur_cap);
+                    cplx* nE = nullptr; int* nI = nullptr;
                     int rc;
-                    if ((rc = dev_alloc(&p->d_prevE, (size_t)nb)) || (rc = dev_alloc(&p->d_prev_iters, (size_t)nb * p->n_contacts))) return rc;
-                    p->prev_cap = nb;
+                    if ((rc = dev_alloc(&nE, (size_t)cap)) || (rc = dev_alloc(&nI, (size_t)cap * p->n_contacts))) { dev_free(nE); return rc; }
+                    if (p->cur_n > 0) {
+                        NEGF_HIP_CHECK(hipMemcpyAsync(nE, p->d_curE, (size_t)p->cur_n * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream));
+                        NEGF_HIP_CHECK(hipMemcpyAsync(nI, p->d_cur_iters, (size_t)p->cur_n * p->n_contacts * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                    }
+                    NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+                    dev_free(p->d_curE); dev_free(p->d_cur_iters);
+                    p->d_curE = nE; p->d_cur_iters = nI; p->cur_cap = cap;
                 }
-                NEGF_HIP_CHECK(hipMemcpyAsync(p->d_prevE, E, (size_t)nb * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream));
-                NEGF_HIP_CHECK(hipMemcpyAsync(p->d_prev_iters, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-                p->prev_n = nb;
-                p->order_n = jobs;
+                NEGF_HIP_CHECK(hipMemcpyAsync(p->d_curE + m0, E, (size_t)nb * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream));
+                NEGF_HIP_CHECK(hipMemcpyAsync(p->d_cur_iters + (size_t)m0 * p->n_contacts, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                p->cur_n = m0 + nb;
             }
             return NEGF_OK;
         }
@@ -490,7 +507,7 @@ int run_assemble(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cplx* E)
     int rc = NEGF_OK;
     if (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) {
         rc = run_sigma_blocks(c, p, nb, E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
-                              c->d_conv + (size_t)m0 * p->n_contacts);
+                              c->d_conv + (size_t)m0 * p->n_contacts, m0);
         if (rc) return rc;
     }
     ProfScope ps(c, "assemble");
@@ -535,7 +552,7 @@ int run_assemble_inverse(negf_ctx* c, SigmaProvider* p, int m0, int nb, const cp
     if (small_path(c, p)) {
         if (p->kind == SK_CHAIN1D || p->kind == SK_BETHE) {
             if ((rc = run_sigma_blocks(c, p, nb, E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
-                                       c->d_conv + (size_t)m0 * p->n_contacts))) return rc;
+                                       c->d_conv + (size_t)m0 * p->n_contacts, m0))) return rc;
         }
         ProfScope ps(c, "small");
         SmallFusedArgs a = small_args(c, p, m0, nb, E);
@@ -760,6 +777,14 @@ int negf_set_small_algo(negf_ctx* c, int algo)
 {
     if (!c || algo < 0 || algo > 1) return NEGF_EINVAL;
     c->small_algo = algo;
+    return NEGF_OK;
+}
+
+int negf_set_chain_round_robin(negf_ctx* c, int quantum, int slots)
+{
+    if (!c || slots < 0) return NEGF_EINVAL;
+    c->chain_rr_quantum = quantum < 0 ? -1 : quantum;
+    c->chain_rr_slots = slots;
     return NEGF_OK;
 }
 
@@ -1083,7 +1108,7 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
         for (int m0 = 0; m0 < m; m0 += chunk) {
             const int nb = std::min(chunk, m - m0);
             if (blocks && (rc = run_sigma_blocks(c, p, nb, E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
-                                                 c->d_conv + (size_t)m0 * p->n_contacts))) return rc;
+                                                 c->d_conv + (size_t)m0 * p->n_contacts, m0))) return rc;
             ProfScope ps(c, "small");
             SmallFusedArgs a = small_args(c, p, m0, nb, E);
             a.w = w + m0; a.partial = c->d_small_part; a.out = m0 == 0 ? out : chunk_sum;
@@ -1406,7 +1431,7 @@ int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const doubl
             if ((rc = dev_alloc(&c->d_small_part, (size_t)m * n2))) return rc;
             c->small_part_cap = (size_t)m * n2;
         }
-        if (blocks && (rc = run_sigma_blocks(c, p, m, Ed, c->d_iters, c->d_conv))) return rc;
+        if (blocks && (rc = run_sigma_blocks(c, p, m, Ed, c->d_iters, c->d_conv, 0))) return rc;
         ProfScope ps(c, "small");
         SmallFusedArgs a = small_args(c, p, 0, m, Ed);
         a.w = wd; a.partial = c->d_small_part; a.out = c->d_seg_out; a.nseg = nseg; a.seg_end = seg_end;
@@ -1590,7 +1615,7 @@ int negf_sigma_eval(negf_ctx* c, int handle, int contact, int m, const double* E
         case SK_CHAIN1D:
         case SK_BETHE: {
             if ((rc = run_sigma_blocks(c, p, nb, c->d_E + m0, c->d_iters + (size_t)m0 * p->n_contacts,
-                                       c->d_conv + (size_t)m0 * p->n_contacts))) return rc;
+                                       c->d_conv + (size_t)m0 * p->n_contacts, m0))) return rc;
             launch_scatter_blocks(c->stream, c->n, nb, c->d_blk, p->blk_stride, p->n_contacts, p->d_nc,
                                   p->d_blk_off, p->d_inds_off, p->d_inds, ct, c->d_A);
             cplx* res = c->d_A;

@@ -92,13 +92,15 @@ struct SigmaProvider {
     unsigned long long lead_hash = 0;
     double eta = 0, conv = 0, relFactor = 0, mix = 0;
     int max_iter = 0, force_iters = -1;
-    // job order learned from the previous evaluation of a grid of order_n jobs (chain kernel)
+    // job order of the next chain launch (predicted on the device)
     int* d_order = nullptr;
-    int order_n = 0, order_cap = 0;
-    // energies and sweep counts of the previous evaluation: the order of a NEW grid is predicted from them
-    cplx* d_prevE = nullptr;
-    int* d_prev_iters = nullptr;
-    int prev_n = 0, prev_cap = 0;
+    int order_cap = 0;
+    // energies and sweep counts of the previous evaluation: the order of a NEW grid is predicted from them.
+    // An evaluation may arrive in several batch chunks (m0 = 0, nb, 2 nb ...): the chunks are appended to
+    // cur*, and the chunk with m0 = 0 of the NEXT evaluation promotes cur* to prev*.
+    cplx *d_prevE = nullptr, *d_curE = nullptr;
+    int *d_prev_iters = nullptr, *d_cur_iters = nullptr;
+    int prev_n = 0, prev_cap = 0, cur_n = 0, cur_cap = 0;
     // BETHE
     std::vector<int> n_atoms;      // atoms per contact
     int* d_atom_orbs = nullptr;    // [total_atoms][9]
@@ -218,6 +220,7 @@ struct negf_ctx {
     cplx* d_small_part = nullptr;  // per-workgroup partial sums of the small fused kernel
     size_t small_part_cap = 0;
     GjSideStreams gj_side;
+    int chain_rr_quantum = -1, chain_rr_slots = 0;   // negf_set_chain_round_robin
     int small_algo = 0;            // 0: n <= 96 takes the fused single-kernel path, 1: never (negf_set_small_algo)
     // pinned host staging of the host-pointer entry points: [E | w] up, [result | info] down, ONE synchronisation
     unsigned char* h_pin = nullptr;
@@ -305,12 +308,15 @@ size_t chain1d_scratch_per_wg(int nc_max);
 bool chain1d_lds_supported(int nc_max);
 // gold_scratch: chain1d_lds_scratch_elems() complex values of lane-private scratch (may be null:
 // the kernel then keeps the old iterate in LDS at a lower occupancy)
-size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb);
+// (+ the job queue of a round-robin launch: rr_quantum < 0 = the default, NEGF_CHAIN_RR)
+size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb, int max_sweeps, int rr_quantum);
 // order: launch slot -> job (energy * n_contacts + contact) or null for launch order
 // gcache / gc_mode: see ChainGEntry -- 0 no cache, 1 store the final iterates, 2 load them and only form Sigma
+// rr_quantum / rr_slots: round-robin execution of a launch with more jobs than resident slots (ChainRsArgs; < 0 / 0:
+// the defaults -- NEGF_CHAIN_RR or 100 sweeps, every slot of the device)
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
                         const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
-                        cplx* gcache = nullptr, int gc_mode = 0);
+                        cplx* gcache = nullptr, int gc_mode = 0, int rr_quantum = -1, int rr_slots = 0);
 // order[0..count) = jobs by decreasing sweep count of the evaluation that just ran (iters[count])
 bool chain1d_order_supported(int count);
 void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order);

@@ -97,6 +97,11 @@ class Engine:
         """0: systems of n <= 96 take the single-kernel path (default), 1: the kernel sequence of larger systems."""
         check(self._lib.negf_set_small_algo(self._ctx, int(algo)), "negf_set_small_algo")
 
+    def set_chain_round_robin(self, quantum=-1, slots=0):
+        """Round-robin execution of chain launches with more fixed points than resident slots: a fixed point runs
+        `quantum` sweeps, then makes room for a waiting one (-1: default, 0: off); `slots` > 0 caps the slots (tests)."""
+        check(self._lib.negf_set_chain_round_robin(self._ctx, int(quantum), int(slots)), "negf_set_chain_round_robin")
+
     def set_gamma_algo(self, algo):
         """0: compact Gamma products where the provider allows (default), 1: dense n x n products."""
         check(self._lib.negf_set_gamma_algo(self._ctx, int(algo)), "negf_set_gamma_algo")

@@ -244,6 +244,15 @@ int negf_set_inverse_algo(negf_ctx* ctx, int algo);
  * HBM; the SCF call pattern is ~10^2 integrals of 2 ... 324 points per density step, scfE.py:301-462); 1 = the
  * assemble / inverse / accumulate kernel sequence through HBM that larger systems use (cross-check, A/B) */
 int negf_set_small_algo(negf_ctx* ctx, int algo);
+/* CHAIN1D launches with more fixed points (energy x contact) than the device holds at once: the fixed points differ
+ * up to 20x in their sweep counts (surfG1D.py:271-288 stops each at its own residual), and the counts are unknown
+ * before the first evaluation.  The kernel runs them ROUND ROBIN: one persistent workgroup per resident slot, a fixed
+ * point runs `quantum` sweeps and, when others wait, goes to the back of a device-side queue with its iterate.  The
+ * chip then stays full until fewer fixed points than slots are left, whatever order they were started in; results
+ * do not depend on it (a fixed point is a sequence of sweeps on its own data).  quantum: < 0 = default (environment
+ * NEGF_CHAIN_RR, else 100), 0 = off (every workgroup one fixed point, started longest first by the counts predicted
+ * from the previous evaluation).  slots: 0 = every resident slot of the device; > 0 caps them (tests). */
+int negf_set_chain_round_robin(negf_ctx* ctx, int quantum, int slots);
 /* G Gamma G^H (integrate.py:81) and Tr[Gamma_L G Gamma_R G^H] (transport.py:156-157):
  * 0 = auto -- when the coupling matrices only touch the contact orbitals (CONST providers
  * with a small support, CHAIN1D / BETHE blocks without an orthogonalisation matrix) the

@@ -565,6 +565,29 @@ def test_chain1d_order_predicted_for_new_grids(engine):
         engine.set_chain_cache(512)
 
 
+def test_chain1d_order_prediction_over_batch_chunks(engine):
+    """A grid evaluated in several batch chunks (negf_set_batch) records the WHOLE evaluation for the next prediction
+    (chunks appended; the chunk at position 0 of the next evaluation promotes the record) -- and, as always, the order
+    changes no result: chunked evaluations of the same and of a moved grid equal the unchunked first evaluation of a
+    fresh provider bit for bit."""
+    nc = 10
+    E1 = np.linspace(-1.5, 1.5, 50)
+    grids = [E1, E1, E1 + 0.013, np.linspace(-1.2, 1.7, 23), E1]
+    _, _, g_seq, _ = _chain_system(3 * nc, nc, 78, 1e-3)
+    engine.set_chain_cache(0)
+    try:
+        for E in grids:
+            engine.set_batch(0)
+            _, _, g_fresh, _ = _chain_system(3 * nc, nc, 78, 1e-3)
+            sig0, it0, cv0 = g_fresh.sigma_batch(E)
+            engine.set_batch(16)                                # 50 energies -> chunks of 16, 16, 16, 2
+            sig1, it1, cv1 = g_seq.sigma_batch(E)
+            assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
+    finally:
+        engine.set_batch(0)
+        engine.set_chain_cache(512)
+
+
 @pytest.mark.parametrize("nc,eta", [(50, 1e-4), (64, 1e-3), (72, 1e-3)])
 def test_chain1d_free_running_large_leads(engine, nc, eta):
     """The reference's stopping rule (surfG1D.py:271-288) at BASELINE C3's lead size and at the two
