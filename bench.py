@@ -466,7 +466,7 @@ def worker_c3(args):
                                        "frac_algorithmic = achieved / peak (8 flop per complex multiply-add, SURVEY 8d)",
                          "mfma_busy_frac": (busy / (avg_chain_ms * 1e-3 * PEAK_CLOCK_HZ * N_SIMD)) if busy else None,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "chain1d_rs_kernel (1-D chain decimation fixed point, one workgroup per energy and contact)",
+                         "kernel": "chain1d_rs_kernel (1-D chain decimation fixed points, energy x contact; one persistent workgroup per resident slot, the fixed points round robin in quanta of 100 sweeps)",
                          "avg_launch_ms": avg_chain_ms, "launches": ch_launches,
                          "sweeps_per_launch": sweeps_per_step / launches_per_step,
                          "flops_per_sweep": 24.0 * NC ** 3, "mfma_flops_per_sweep": per_sweep,

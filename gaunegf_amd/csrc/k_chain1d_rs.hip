@@ -937,7 +937,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
     // place of B:  X = t g (row tiles) -> Ws,  Sigma = X t^H (column tiles) -> global.
     bool need_job = true;
     while (true) {
-        if (need_job) {
+        if (__builtin_expect(need_job, 0)) {
             if (!next_job()) break;                     // (round robin: the queue is empty -- every job is finished or held by a running workgroup)
             need_job = false;
         }
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
             if (!first) ++count;
             first = false;
         }
-        if (skip) {
+        if (__builtin_expect(skip, 0)) {
             skip = false;
         } else if (gc_hit || (a.force_iters >= 0 ? count >= a.force_iters : !(over && count < a.max_iter))) {
             final_pass = true;
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
                 cplx* gcj = a.gcache + (size_t)b * a.blk_stride + off;                              //  since the barrier that ends gather_mix)
                 for (int t = tid; t < n * n; t += RS_THREADS) { const int i = t / n; gcj[t] = Ws[i * P + (t - i * n)]; }
             }
-        } else if (rr && count >= q_end) {
+        } else if (__builtin_expect(rr && count >= q_end, 0)) {
             // the quantum is over.  Nobody waiting: carry on.  Otherwise the iterate goes to the job's output block (g sits in
             // Ws, complete since the barrier that ends gather_mix), the job to the back of the queue, and this workgroup
             // takes the job at the front
