@@ -1,40 +1,18 @@
 // Job order of the 1-D chain fixed-point kernel (k_chain1d_rs.hip): the jobs of a launch differ by up to 20x in length
 // (100 ... 2000 sweeps) and are started LONGEST FIRST, by sweep counts known or predicted from the previous evaluation of
-// the provider (gauNEGF/surfG1D.py:271-288 runs every energy until ITS OWN stopping rule fires; the order never changes a
+// the provider -- which spreads the long jobs of a launch smaller than the chip over the compute units, and is the initial
+// queue of a larger one (that one runs round robin and does not depend on it) (gauNEGF/surfG1D.py:271-288 runs every energy until ITS OWN stopping rule fires; the order never changes a
 // result).  Kept apart from the kernel itself so that the predictor can change without touching the profiled source.
 #include "negf_common.h"
 #include <algorithm>
 
 namespace {
 
-// order[0..count) = job indices by decreasing sweep count (ties: increasing index): one workgroup, bitonic
-// sort of the packed keys in LDS.  count <= RS_ORDER_MAX.
 constexpr int RS_ORDER_MAX = 16384;
-__global__ __launch_bounds__(1024) void chain1d_order_kernel(const int* __restrict__ iters, int count, int* __restrict__ order)
-{
-    extern __shared__ int keys[];
-    int np2 = 1;
-    while (np2 < count) np2 <<= 1;
-    for (int t = threadIdx.x; t < np2; t += blockDim.x)
-        keys[t] = t < count ? min(iters[t], 131071) * RS_ORDER_MAX + (RS_ORDER_MAX - 1 - t) : -1;    // 17 + 14 bits: no overflow for any max_iter
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < np2; t += blockDim.x) {
-                const int u = t ^ j;
-                if (u > t) {
-                    const bool desc = (t & k) == 0;
-                    const int a = keys[t], b = keys[u];
-                    if (desc ? a < b : a > b) { keys[t] = b; keys[u] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int t = threadIdx.x; t < count; t += blockDim.x) order[t] = RS_ORDER_MAX - 1 - (keys[t] % RS_ORDER_MAX);
-}
 
-// The same order for a grid that was NOT evaluated before (a Fermi search moves its contour, an adaptive grid doubles):
-// the sweep count of a job is predicted from the previous evaluation -- the counts vary smoothly with the energy (they
+// order[0..count) = job indices by decreasing PREDICTED sweep count (ties: increasing index): one workgroup, bitonic sort
+// of packed keys in LDS, count <= RS_ORDER_MAX.  Also for a grid that was NOT evaluated before (a Fermi search moves its
+// contour, an adaptive grid doubles): the sweep count of a job is predicted from the previous evaluation -- the counts vary smoothly with the energy (they
 // follow the lead's bands).  Round 4: where the previous grid brackets the new energy on a line of constant Im E (the
 // real-axis grids: the expensive ones), the counts of the two bracketing energies are interpolated linearly in Re E,
 // per contact; elsewhere (contour points, energies outside the previous range) the count of the nearest previous energy
@@ -104,11 +82,3 @@ void launch_chain1d_predict_order(hipStream_t st, const cplx* prevE, const int* 
     hipLaunchKernelGGL(chain1d_predict_order_kernel, dim3(1), dim3(1024), (size_t)np2 * sizeof(int), st, prevE, prev_iters,
                        prev_n, n_contacts, E, nb, order);
 }
-
-void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order)
-{
-    int np2 = 1;
-    while (np2 < count) np2 <<= 1;
-    hipLaunchKernelGGL(chain1d_order_kernel, dim3(1), dim3(1024), (size_t)np2 * sizeof(int), st, iters, count, order);
-}
-

@@ -1088,6 +1088,9 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
             hipLaunchKernelGGL(rs_rr_init_kernel, dim3((rr_cap + 255) / 256), dim3(256), 0, st, aa.rr_q, rr_cap, (unsigned)jobs);
             grid = dim3(slots, 1);
         } else aa.rr_quantum = 0;
+        static int log_env = -1;
+        if (log_env < 0) log_env = getenv("NEGF_CHAIN_LOG") ? 1 : 0;
+        if (log_env) fprintf(stderr, "[chain launch] jobs %d slots %d quantum %d order %d gc_mode %d\n", jobs, slots, aa.rr_quantum, aa.order ? 1 : 0, aa.gc_mode);
         hipLaunchKernelGGL(kern, grid, dim3(RS_THREADS), smem, st, aa, E, blk, iters, conv);
     };
     constexpr int OCC_MAX = T16 <= 2 ? 4 : 3;          // register budget: 128 VGPRs (T16 <= 2), 168 above

@@ -317,9 +317,8 @@ size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb, int max_swe
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
                         const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
                         cplx* gcache = nullptr, int gc_mode = 0, int rr_quantum = -1, int rr_slots = 0);
-// order[0..count) = jobs by decreasing sweep count of the evaluation that just ran (iters[count])
+// order[0..count) = jobs by decreasing sweep count predicted from the previous evaluation (k_chain1d_order.hip)
 bool chain1d_order_supported(int count);
-void launch_chain1d_order(hipStream_t st, const int* iters, int count, int* order);
 void launch_chain1d_predict_order(hipStream_t st, const cplx* prevE, const int* prev_iters, int prev_n, int n_contacts,
                                   const cplx* E, int nb, int* order);
 

@@ -2,6 +2,7 @@
 0.013 eV -- B evaluated by a fresh provider (launch order) against B evaluated after A (order predicted from A)."""
 import sys, time, numpy as np
 import os; os.environ.setdefault("NEGF_CHAIN_CACHE", "0")      # time the fixed point, not the g(E) cache
+os.environ.setdefault("NEGF_CHAIN_RR", "0")                    # ... one workgroup per job: the round-robin launch does not depend on the order
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from gaunegf_amd.surfG1D import surfG

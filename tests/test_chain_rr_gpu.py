@@ -35,7 +35,7 @@ def rr(engine):
 def test_round_robin_changes_no_bit(rr, ncL, ncR, eta, M):
     """Free-running fixed points (lengths from tens of sweeps to the 2000 cap) on 3 ... 11 slots with quanta of
     1 ... 400 sweeps against the plain launch (one workgroup per fixed point): Sigma, counts and flags bit for bit.
-    The second evaluation of a provider also starts from a PREDICTED order (the queue's initial content)."""
+    (Evaluated twice per provider: the plain launch of the second evaluation starts from a predicted order.)"""
     make = _leads(ncL + ncR + 9, ncL, ncR, 500 + ncL, eta)
     E = np.linspace(-1.6, 1.5, M) + 0.0j
     E[M // 2] += 0.2j                              # (one energy off the axis: a short fixed point)

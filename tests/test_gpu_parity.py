@@ -554,6 +554,7 @@ def test_chain1d_order_predicted_for_new_grids(engine):
              np.linspace(-0.2, 0.2, 5), np.linspace(-1.5, 1.5, 37), np.linspace(-1.6, 1.4, 130) + 0.05j]
     _, _, g_seq, _ = _chain_system(3 * nc, nc, 77, 1e-3)
     engine.set_chain_cache(0)                                   # every evaluation runs the fixed point (no g(E) cache hits)
+    engine.set_chain_round_robin(0, 0)                          # (the round-robin launch needs and takes no order)
     try:
         for E in grids:
             _, _, g_fresh, _ = _chain_system(3 * nc, nc, 77, 1e-3)
@@ -562,6 +563,7 @@ def test_chain1d_order_predicted_for_new_grids(engine):
             assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
             assert it1.max() > it1.min()                        # (the jobs do differ in length)
     finally:
+        engine.set_chain_round_robin(-1, 0)
         engine.set_chain_cache(512)
 
 
@@ -575,6 +577,7 @@ def test_chain1d_order_prediction_over_batch_chunks(engine):
     grids = [E1, E1, E1 + 0.013, np.linspace(-1.2, 1.7, 23), E1]
     _, _, g_seq, _ = _chain_system(3 * nc, nc, 78, 1e-3)
     engine.set_chain_cache(0)
+    engine.set_chain_round_robin(0, 0)
     try:
         for E in grids:
             engine.set_batch(0)
@@ -585,6 +588,7 @@ def test_chain1d_order_prediction_over_batch_chunks(engine):
             assert np.array_equal(it0, it1) and np.array_equal(cv0, cv1) and np.array_equal(sig0, sig1), E.size
     finally:
         engine.set_batch(0)
+        engine.set_chain_round_robin(-1, 0)
         engine.set_chain_cache(512)
 
 
@@ -1074,8 +1078,8 @@ def test_config_C3_free_running_at_the_sweep_cap(engine):
     points stop at the 2000-sweep cap, where the iterate is not a fixed point.  Six such energies and two that
     converge, picked from a 32-point probe of the 2000-point grid, against the oracle: sweep counts (+-1 only where
     the threshold is crossed; at the cap both run exactly 2000), Sigma(E), and GrInt on that sub-grid.  The grid is
-    evaluated twice -- the second launch runs longest-first in the order learned from the first -- and must
-    reproduce Sigma and the counts bit for bit."""
+    evaluated twice with the round robin off -- the second launch then runs longest-first in the order learned from
+    the first -- and must reproduce Sigma and the counts bit for bit; then with the round robin forced on 5 slots."""
     from gaunegf_amd.integrate import GrInt
     F, S, g_dev, g_ref = _chain_system(500, 50, 3, 1e-4)
     E, w = oracle.real_axis_grid(-2.0, 2.0, 2000, 0.0)
@@ -1084,13 +1088,18 @@ def test_config_C3_free_running_at_the_sweep_cap(engine):
     at_cap = it.max(axis=1) >= 2000
     assert at_cap.sum() >= 6 and (~at_cap).sum() >= 2, it.max(axis=1)
     sub = np.concatenate([probe[at_cap][:6], probe[~at_cap][:2]])
-    engine.set_chain_cache(0)                                     # both evaluations run the fixed point
+    engine.set_chain_cache(0)                                     # all evaluations run the fixed point
+    engine.set_chain_round_robin(0, 0)
     try:
         sig, iters, cv = g_dev.sigma_batch(E[sub])
         sig2, iters2, cv2 = g_dev.sigma_batch(E[sub])             # learned (longest-first) launch order
+        engine.set_chain_round_robin(150, 5)
+        sig5, iters5, cv5 = g_dev.sigma_batch(E[sub])             # 16 fixed points through 5 slots, quanta of 150 sweeps
     finally:
+        engine.set_chain_round_robin(-1, 0)
         engine.set_chain_cache(512)
     assert np.array_equal(iters, iters2) and np.array_equal(cv, cv2) and np.array_equal(sig, sig2)
+    assert np.array_equal(iters, iters5) and np.array_equal(cv, cv5) and np.array_equal(sig, sig5)
     sig3, iters3, cv3 = g_dev.sigma_batch(E[sub])                 # fills the g(E) cache ...
     sig4, iters4, cv4 = g_dev.sigma_batch(E[sub])                 # ... and is served from it: the same bits again
     assert engine.chain_cache_stats()["hits"] >= 1
