@@ -294,6 +294,9 @@ void launch_gamma_small(hipStream_t st, int K, int c0, int c1, int nb, const int
 void launch_gather_block(hipStream_t st, int n, int nr, int nc, int nb, const cplx* G, size_t strideG,
                          const int* ridx, const int* cidx, cplx* out, size_t out_stride);
 
+// dst_b = src_b^H (n x n, contiguous, same stride for both)
+void launch_conj_transpose(hipStream_t st, int n, int nb, const cplx* src, size_t stride, cplx* dst);
+
 // dense Sigma from contact blocks: out[b] = scatter-add of selected contacts (contact<0: all)
 void launch_scatter_blocks(hipStream_t st, int n, int nb, const cplx* blk, int blk_stride,
                            int n_contacts, const int* d_nc, const int* d_blk_off,

@@ -504,6 +504,45 @@ def test_compact_gamma_products_match_dense_and_oracle(engine):
             assert abs(T[0][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
 
 
+@pytest.mark.parametrize("N", [650, 720])
+def test_dense_hermitian_products_read_a_stored_conjugate_transpose(engine, N):
+    """From n = 640 up the dense products X G^H (G Gamma G^H, integrate.py:79-81; Tr[Gamma_L G Gamma_R G^H],
+    transport.py:156-157) read G^H as a stored operand (one transposition pass over G per batch) instead of
+    conjugate-transposing tiles of G on the fly; the Hermitian form still computes the upper block tiles only and
+    mirrors the rest (N = 650: 11 x 11 block tiles, the odd enumeration, an edge block of 10 columns; 720: 12 x 12, edge 16).
+    Dense products forced (negf_set_gamma_algo 1) against the compact path and the oracle."""
+    from gaunegf_amd.integrate import GrLessInt
+    E = np.linspace(-2, 2, 6); w = np.full(6, 4.0 / 6) + 0j
+    F, S, g_dev, g_ref = _const_provider(N, 77 + N)
+    for ind in (None, 0, -1):
+        res = {}
+        for algo in (0, 1):
+            engine.set_gamma_algo(algo)
+            try:
+                res[algo] = GrLessInt(F, S, g_dev, E, w, ind)
+            finally:
+                engine.set_gamma_algo(0)
+        ref = oracle.GrLessInt(F, S, g_ref, E, w, ind)
+        assert rel_fro(res[0], res[1]) < 1e-12, ind
+        assert rel_fro(res[1], ref) < TOL, ind
+        assert rel_fro(res[1], res[1].conj().T) < 1e-13, ind          # (the mirrored half)
+    h = g_dev._negf_lower(engine)
+    engine.set_system(F, S)
+    T = {}
+    for algo in (0, 1):
+        engine.set_gamma_algo(algo)
+        try:
+            T[algo] = engine.transmission(h, 0, 1, E)
+        finally:
+            engine.set_gamma_algo(0)
+    assert np.max(np.abs(T[0] - T[1])) < 1e-12 * max(1.0, np.max(np.abs(T[1])))
+    for k in (0, 5):
+        sg = [np.asarray(g_ref.sigma(E[k], i)) for i in (0, 1)]
+        gam = [1j * (x - x.conj().T) for x in sg]
+        tref = oracle.transmission_restricted(E[k], F, S, sg[0] + sg[1], gam[0], gam[1])
+        assert abs(T[1][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
+
+
 @pytest.mark.parametrize("nc", [4, 8, 9, 10, 16, 17, 18, 20, 24, 25, 33, 35, 40, 41, 48, 49, 50, 51, 56, 57, 63, 64, 65, 80])
 def test_chain1d_fixed_trip_count(engine, nc):
     """Same number of sweeps on both sides -> the iterate itself must agree.  n_c = 33/48 and 50/64
