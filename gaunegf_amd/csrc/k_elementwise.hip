@@ -208,38 +208,6 @@ void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cpl
     hipLaunchKernelGGL(cadd_kernel, dim3((unsigned)((count + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, st, count, a, b, out);
 }
 
-// out_b = src_b^H for nb n x n matrices: 64 x 64 tiles through LDS (pitch 65), rows of 1 KB read and written.
-// The products X G^H of the dense G Gamma G^H and of the transmission read G^H as a PLAIN second operand this way:
-// the K-tile of a plain operand is 16 rows x 1 KB and mostly served by the compute unit's L1, the K-tile of an operand
-// conjugate-transposed on the fly is 64 rows x 256 B and costs the L2 twice the requests (n = 1000, 256 products:
-// 25.8 against 31.3 ms); one pass over G (8 GB per 256 matrices of n = 1000: 2.3 ms) is cheaper than the
-// difference from n ~ 640 up.
-__global__ __launch_bounds__(256) void conj_transpose_kernel(int n, const cplx* __restrict__ src, size_t stride, cplx* __restrict__ dst)
-{
-    __shared__ cplx T[64 * 65];
-    const cplx* A = src + (size_t)blockIdx.z * stride;
-    cplx* B = dst + (size_t)blockIdx.z * stride;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, cc = c0 + tx;
-        if (r < n && cc < n) T[i * 65 + tx] = A[(size_t)r * n + cc];
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int r = c0 + i, cc = r0 + tx;                 // row / column of the transposed matrix
-        if (r < n && cc < n) B[(size_t)r * n + cc] = cconj(T[tx * 65 + i]);
-    }
-}
-
-void launch_conj_transpose(hipStream_t st, int n, int nb, const cplx* src, size_t stride, cplx* dst)
-{
-    if (nb <= 0 || n <= 0) return;
-    hipLaunchKernelGGL(conj_transpose_kernel, dim3((n + 63) / 64, (n + 63) / 64, nb), dim3(256), 0, st, n, src, stride, dst);
-}
-
 // -------------------------------------------------------------- accumulate
 // acc[i] += sum_b w[b] * X[b][i] in a FIXED order (bitwise reproducible from run to run):
 // the batch is cut into chunks of ACC_CHUNK energies; pass 1 reduces each chunk into

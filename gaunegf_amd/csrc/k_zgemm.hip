@@ -20,6 +20,13 @@
 // integrate.py:79-81: X G^H with X = G Gamma): only the block tiles on and above the diagonal are computed, every block
 // above it also stores its conjugate transpose -- the same sums, each taken once (n = 1000: 136 of 256 block tiles).
 //
+// opB bit 4: the result is stored CONJUGATE-TRANSPOSED, C = (A op(B))^H (N x M, leading dimension ldc), every 16 x 16
+// sub-tile transposed through a per-wave LDS patch so that the stores stay 256-byte runs.  The products X G^H of
+// G Gamma G^H and of the transmission are taken as G X^H with X^H = (G Gamma)^H written this way by the first product
+// (Gamma Hermitian): the K-tile of a PLAIN second operand is 16 rows x 1 KB and mostly served by the compute unit's L1,
+// the K-tile of an operand conjugate-transposed on the fly is 64 rows x 256 B and costs the L2 twice the requests
+// (n = 1000, 256 products: 25.8 against 31.3 ms).
+//
 // Workgroup = 256 threads = 4 waves; block tile 64 x 64, wave tile 32 x 32
 // (2 x 2 MFMA tiles, 64 accumulator VGPRs), K tile 16 staged through LDS.
 #include "negf_common.h"
@@ -79,6 +86,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
     __shared__ cplx Bs[ZG_BK * ZG_BPITCH];      // Bs[k][j]  (already op()'ed)
 
     const bool herm = (opB_arg & 2) != 0;       // Hermitian product: blocks below the diagonal are mirrored, not computed
+    const bool store_t = (opB_arg & 4) != 0;    // the result is stored conjugate-transposed (not with herm)
     const int opB = opB_arg & 1;
     // Hermitian form: the grid is the upper triangle itself, row by row (gridDim.x = T (T + 1) / 2 block tiles) -- a
     // full T x T grid with the lower blocks returning at once loads the XCDs (block index mod 8) unevenly and ran
@@ -174,18 +182,20 @@ __global__ __launch_bounds__(256, 3) void zgemm_mfma_kernel(
         __syncthreads();
     }
     // ---- store: lane l, reg r -> row (l>>4) + 4r, col l&15 ; 16 lanes write 256 contiguous bytes
+    if (!store_t) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = row0 + wr + a * 16 + fk + 4 * r;
-                const int gj = col0 + wc + c * 16 + fi;
-                if (gi < M && gj < N)
-                    C[(size_t)gi * ldc + gj] = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
-            }
-    if (mirror) {
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = row0 + wr + a * 16 + fk + 4 * r;
+                    const int gj = col0 + wc + c * 16 + fi;
+                    if (gi < M && gj < N)
+                        C[(size_t)gi * ldc + gj] = cmake(s1[a][c][r] - s2[a][c][r], s3[a][c][r] - s1[a][c][r] - s2[a][c][r]);
+                }
+    }
+    if (mirror || store_t) {
         // the conjugate transpose of the block, transposed through LDS (the A staging area is free after the K loop:
         // one 16 x 17 patch per wave) so that 16 lanes again write 256 contiguous bytes -- written straight from the
         // accumulator layout the mirror image is 64-byte pieces in 16 different rows, and the two Hermitian products
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
     __shared__ cplx Bs[ZG_BK * ZF_BPITCH];       // Bs[k][j]  (already op()'ed)
     __shared__ cplx Ts[ZF_WAVES * 16 * 17];      // per-wave transpose patch of the Hermitian mirror image
     const bool herm = (opB_arg & 2) != 0;        // see zgemm_mfma_kernel (M == N: the row and column blocks coincide)
+    const bool store_t = (opB_arg & 4) != 0;
     const int opB = opB_arg & 1;
     int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
     if (herm && !zg_herm_decode(nbn, nbatch, (int)blockIdx.x, &by, &bx, &b)) return;
@@ -321,12 +332,14 @@ __global__ __launch_bounds__(ZF_THREADS) void zgemm_flex_kernel(
         const int t = wave + s * ZF_WAVES;
         if (t < ntiles) {
             const int ti = t / tn, tj = t - ti * tn;
+            if (!store_t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = row0 + ti * 16 + fk + 4 * r, gj = col0 + tj * 16 + fi;
-                if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = row0 + ti * 16 + fk + 4 * r, gj = col0 + tj * 16 + fi;
+                    if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = cmake(s1[s][r] - s2[s][r], s3[s][r] - s1[s][r] - s2[s][r]);
+                }
             }
-            if (mirror) {                                    // (wave-uniform) the conjugate transpose, through LDS: see zgemm_mfma_kernel
+            if (mirror || store_t) {                                    // (wave-uniform) the conjugate transpose, through LDS: see zgemm_mfma_kernel
                 cplx* T = Ts + wave * (16 * 17);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(256) void zgemm_valu_kernel(
     cplx* __restrict__ Call, int ldc, size_t strideC)
 {
     const int opB = opB_arg & 1;                 // (the Hermitian hint is not used: every element is computed)
+    const bool store_t = (opB_arg & 4) != 0;
     __shared__ cplx As[32][17];
     __shared__ cplx Bs[16][33];
     const int b = blockIdx.z;
@@ -401,7 +415,10 @@ __global__ __launch_bounds__(256) void zgemm_valu_kernel(
     for (int a = 0; a < 2; ++a)
         for (int c = 0; c < 2; ++c) {
             const int gi = row0 + ty + 16 * a, gj = col0 + tx + 16 * c;
-            if (gi < M && gj < N) C[(size_t)gi * ldc + gj] = acc[a][c];
+            if (gi < M && gj < N) {
+                if (store_t) C[(size_t)gj * ldc + gi] = cconj(acc[a][c]);
+                else C[(size_t)gi * ldc + gj] = acc[a][c];
+            }
         }
 }
 
@@ -421,10 +438,10 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
                   cplx* C, int ldc, size_t strideC)
 {
     if (M <= 0 || N <= 0 || nb <= 0) return;
-    if ((opB & 2) && M != N) opB &= 1;           // the Hermitian form needs a square result
+    if ((opB & 2) && (M != N || (opB & 4))) opB &= ~2;   // the Hermitian form needs a square result, stored as it is
     static int herm_env = -1;                    // NEGF_ZGEMM_HERM=0: compute Hermitian products in full (A/B, tests)
     if (herm_env < 0) { const char* e = getenv("NEGF_ZGEMM_HERM"); herm_env = e ? atoi(e) : 1; }
-    if (!herm_env) opB &= 1;
+    if (!herm_env) opB &= ~2;
     {   // flop accounting (negf_common.h, FlopCount): 16 x 16 sub-tiles that hold part of the result, K padded to the
         // staged K-tile, three real products per sub-tile and k-step; a Hermitian product runs the sub-tiles of the
         // block tiles on and above the diagonal only

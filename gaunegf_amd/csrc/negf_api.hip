@@ -1140,15 +1140,6 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
     return NEGF_OK;
 }
 
-// X G^H of the dense products: from this size up G^H is formed once per batch (launch_conj_transpose) and read as a plain
-// operand (NEGF_ZGEMM_GT=0: always conjugate-transposed on the fly inside the product)
-static bool gt_operand(int n)
-{
-    static int env = -1;
-    if (env < 0) { const char* e = getenv("NEGF_ZGEMM_GT"); env = e ? atoi(e) : 1; }
-    return env != 0 && n >= 640;            // (n = 1000: 44.2 -> 43.4 ms per 256 product pairs, n = 500: no gain)
-}
-
 // sum_m w_m G Gamma_c G^H over the energies E[0..m) (device pointers).  nseg == 0: one sum into out [n*n]; nseg > 0: the
 // energies are nseg consecutive segments ending at seg_end[s] (host array) and out [nseg][n*n] receives one sum each.
 static int gless_core(negf_ctx* c, SigmaProvider* p, int contact, int m, const cplx* E, const cplx* w, cplx* out,
@@ -1188,28 +1179,26 @@ static int gless_core(negf_ctx* c, SigmaProvider* p, int contact, int m, const c
         }
         size_t gs = 0;
         const cplx* gam = nullptr;
-        const cplx* res = c->W1;
         { ProfScope ps(c, "gamma"); if ((rc = run_gamma(c, p, contact, m0, nb, c->W1, c->W2, &gam, &gs))) return rc; }
         {
             ProfScope ps(c, "zgemm");
-            // W2 = G Gamma ; W1 = W2 G^H   (integrate.py:81)
-            launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, gam, n, gs, 0, c->W2, n, n2);
-            // (G Gamma G^H is Hermitian -- Gamma = i (Sigma - Sigma^H) is, element by element -- : upper block tiles
-            //  computed, lower ones mirrored)
-            // (coupling matrices handed in by the caller -- pre_is_gamma -- need not be Hermitian: the full product)
+            // G Gamma G^H (integrate.py:81).  Gamma = i (Sigma - Sigma^H) is Hermitian, element by element, and so is the
+            // result: W2 = (G Gamma)^H -- the first product stores its result conjugate-transposed -- and W1 = G W2
+            // ( = G Gamma^H G^H), upper block tiles computed, lower ones mirrored.  Both products read their second
+            // operand in the plain form (k_zgemm.hip: the operand conjugate-transposed on the fly costs the L2 twice
+            // the requests).
+            // (coupling matrices handed in by the caller -- pre_is_gamma -- need not be Hermitian: X = G Gamma, then
+            //  the full product X G^H)
             const bool full = p->kind == SK_PRECOMPUTED && p->pre_is_gamma;
-            if (!full && gt_operand(n)) {
-                // G^H as a stored operand (launch_conj_transpose: the plain form of the product reads its second operand
-                // with half the L2 requests): Gamma's buffer W1 is free once X = G Gamma exists, and the product may
-                // overwrite G, which it no longer reads
-                launch_conj_transpose(c->stream, n, nb, c->G, n2, c->W1);
-                launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->W1, n, n2, 2, c->G, n, n2);
-                res = c->G;
+            if (!full) {
+                launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, gam, n, gs, 4, c->W2, n, n2);
+                launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, c->W2, n, n2, 2, c->W1, n, n2);
             } else {
-                launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, full ? 1 : 3, c->W1, n, n2);
+                launch_zgemm(c->stream, n, n, n, nb, c->G, n, n2, gam, n, gs, 0, c->W2, n, n2);
+                launch_zgemm(c->stream, n, n, n, nb, c->W2, n, n2, c->G, n, n2, 1, c->W1, n, n2);
             }
         }
-        accumulate(res, m0, nb);
+        accumulate(c->W1, m0, nb);
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
@@ -1291,21 +1280,22 @@ int negf_transmission_dev(negf_ctx* c, int handle, int contact_L, int contact_R,
         if (spin_mode == NEGF_SPIN_RESTRICTED) {
             {
                 ProfScope ps(c, "zgemm");
-                // T = Re Tr[Gamma_L G Gamma_R G^H]  (transport.py:156-157) as  X = G Gamma_R ;  M = X G^H -- Hermitian,
-                // as Gamma_R is: upper block tiles only (launch_zgemm opB = 3) -- ;  T = Re sum Gamma_L,ij conj(M_ij)
+                // T = Re Tr[Gamma_L G Gamma_R G^H]  (transport.py:156-157) as  X = (G Gamma_R)^H ;  M = G X -- Hermitian,
+                // as Gamma_R is: upper block tiles only (launch_zgemm opB bit 2) -- ;  T = Re sum Gamma_L,ij conj(M_ij)
                 // ( = Re Tr[Gamma_L M], M_ji = conj(M_ij)): one and a half dense products instead of two
                 // (explicit Gamma matrices handed in by the caller -- negf_sigma_precomputed with gammas, the
                 //  reference's _transmission_kernel_restricted(E, F, S, sigma, gamma1, gamma2) -- need not be
                 //  Hermitian: M is then computed in full, opB = 1, and T = Re Tr[Gamma_L M] = Re sum Gamma_L,ij M_ji
                 //  is taken with M^H: sum Re(Gamma_L,ij conj(M^H_ij)))
                 const bool herm_ok = !(p->kind == SK_PRECOMPUTED && p->pre_is_gamma);
-                launch_zgemm(c->stream, n, n, n, nb, G, n, n2, gamR, n, gsR, 0, X, n, n2);
-                if (herm_ok && gt_operand(n)) {
-                    cplx* Gt = c->W2 + n2 * half;         // (the free half of X's buffer; see gless_core)
-                    launch_conj_transpose(c->stream, n, nb, G, n2, Gt);
-                    launch_zgemm(c->stream, n, n, n, nb, X, n, n2, Gt, n, n2, 2, Y, n, n2);          // Y = M = X G^H
-                } else if (herm_ok) launch_zgemm(c->stream, n, n, n, nb, X, n, n2, G, n, n2, 3, Y, n, n2);   // Y = M = X G^H
-                else launch_zgemm(c->stream, n, n, n, nb, G, n, n2, X, n, n2, 1, Y, n, n2);           // Y = G X^H = M^H
+                if (herm_ok) {
+                    // X = (G Gamma_R)^H stored by the first product, M = G X: both second operands in the plain form
+                    launch_zgemm(c->stream, n, n, n, nb, G, n, n2, gamR, n, gsR, 4, X, n, n2);
+                    launch_zgemm(c->stream, n, n, n, nb, G, n, n2, X, n, n2, 2, Y, n, n2);           // Y = M = G Gamma_R G^H
+                } else {
+                    launch_zgemm(c->stream, n, n, n, nb, G, n, n2, gamR, n, gsR, 0, X, n, n2);
+                    launch_zgemm(c->stream, n, n, n, nb, G, n, n2, X, n, n2, 1, Y, n, n2);           // Y = G X^H = M^H
+                }
             }
             ProfScope ps(c, "trace");
             launch_trace_dot(c->stream, n, n, nb, gamL, n, gsL, Y, n, n2, T_dev + m0, 1);

@@ -272,8 +272,9 @@ void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cpl
 size_t accumulate_scratch_elems(int n2, int nb);
 
 // C[b] (M x N) = A[b] (M x K) * op(B[b]);  a batch stride of 0 broadcasts one matrix.
-// opB: 0 -> B is K x N (ldb >= N); 1 -> op(B) = B^H with B stored N x K (ldb >= K); 3 -> as 1, and the caller states
-// that the (square) product is Hermitian: block tiles above the diagonal are computed and mirrored, those below skipped.
+// opB bit 1 (value 1): op(B) = B^H with B stored N x K (ldb >= K), else B is K x N (ldb >= N); bit 2 (value 2): the
+// caller states that the (square) product is Hermitian -- block tiles above the diagonal are computed and mirrored, those
+// below skipped; bit 4 (value 4): the result is stored conjugate-transposed, C = (A op(B))^H (N x M; not with bit 2).
 void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
                   const cplx* A, int lda, size_t strideA,
                   const cplx* B, int ldb, size_t strideB, int opB,
@@ -293,9 +294,6 @@ void launch_gamma_small(hipStream_t st, int K, int c0, int c1, int nb, const int
                         const int* d_inds_off, const cplx* blk, size_t blk_stride, cplx* out, size_t out_stride);
 void launch_gather_block(hipStream_t st, int n, int nr, int nc, int nb, const cplx* G, size_t strideG,
                          const int* ridx, const int* cidx, cplx* out, size_t out_stride);
-
-// dst_b = src_b^H (n x n, contiguous, same stride for both)
-void launch_conj_transpose(hipStream_t st, int n, int nb, const cplx* src, size_t stride, cplx* dst);
 
 // dense Sigma from contact blocks: out[b] = scatter-add of selected contacts (contact<0: all)
 void launch_scatter_blocks(hipStream_t st, int n, int nb, const cplx* blk, int blk_stride,

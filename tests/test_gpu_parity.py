@@ -504,12 +504,13 @@ def test_compact_gamma_products_match_dense_and_oracle(engine):
             assert abs(T[0][k] - tref) < 1e-8 * max(1.0, abs(tref)), k
 
 
-@pytest.mark.parametrize("N", [650, 720])
+@pytest.mark.parametrize("N", [200, 330, 650, 720])
 def test_dense_hermitian_products_read_a_stored_conjugate_transpose(engine, N):
-    """From n = 640 up the dense products X G^H (G Gamma G^H, integrate.py:79-81; Tr[Gamma_L G Gamma_R G^H],
-    transport.py:156-157) read G^H as a stored operand (one transposition pass over G per batch) instead of
+    """The dense products X G^H (G Gamma G^H, integrate.py:79-81; Tr[Gamma_L G Gamma_R G^H],
+    transport.py:156-157) are taken as G X^H with X^H stored by the first product (both second operands plain) instead of
     conjugate-transposing tiles of G on the fly; the Hermitian form still computes the upper block tiles only and
-    mirrors the rest (N = 650: 11 x 11 block tiles, the odd enumeration, an edge block of 10 columns; 720: 12 x 12, edge 16).
+    mirrors the rest (N = 200: the flexible-block kernel; 330: 6 x 6 block tiles, an edge block of 10 columns; 650: 11 x 11,
+    the odd enumeration; 720: 12 x 12, edge 16).
     Dense products forced (negf_set_gamma_algo 1) against the compact path and the oracle."""
     from gaunegf_amd.integrate import GrLessInt
     E = np.linspace(-2, 2, 6); w = np.full(6, 4.0 / 6) + 0j
