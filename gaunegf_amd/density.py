@@ -483,6 +483,7 @@ def _compute_dos_at_energy(E, F, S, sigma_total):
 # calls (Engine.set_system skips identical uploads), only mu changes.
 # --------------------------------------------------------------------------- #
 from .config import FERMI_CALCULATION_TOL, FERMI_SEARCH_CYCLES, ENERGY_MIN   # noqa: E402
+from ._hostblas import limited_call                                          # noqa: E402
 
 FERMI_DEBUG = False
 
@@ -494,6 +495,7 @@ def _orbital_energies(F, S, hermitian=False):
     return np.sort(np.real(vals))
 
 
+@limited_call
 def calcEmin(F, S, g, tol=FERMI_CALCULATION_TOL, maxN=MAX_CYCLES):
     """Lower contour bound: walk down in 1 eV steps from (lowest orbital - 5 eV) until the
     DOS falls below tol (density.py:821-836).

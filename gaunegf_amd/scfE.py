@@ -22,6 +22,7 @@ every energy-grid integral runs on the GPU engine through ``gaunegf_amd.density`
 import numpy as np
 from scipy.linalg import fractional_matrix_power
 
+from ._hostblas import limited_call
 from .config import (ADAPTIVE_INTEGRATION_TOL, ENERGY_MIN, FERMI_CALCULATION_TOL, TEMPERATURE, SCF_DAMPING,
                      SCF_CONVERGENCE_TOL, SCF_MAX_CYCLES, PULAY_MIXING_SIZE)
 from .density import (bisectFermi, density, calcEmin, calcFermiBisect, calcFermiMuller, calcFermiPolyFit, calcFermiSecant,
@@ -32,6 +33,7 @@ har_to_eV = 27.211386   # eV/Hartree (scfE.py:44)
 
 
 class NEGFE:
+    @limited_call
     def __init__(self, F_eV, S, g, ne, spin='r', T=TEMPERATURE, Eminf=ENERGY_MIN, fock_builder=None):
         """``g``: contact object with the reference's protocol (sigma, sigmaTot, setF, F, S);
         ``fock_builder(P) -> F_eV``: optional model replacing Gaussian's PToFock for ``SCF``."""
@@ -117,6 +119,7 @@ class NEGFE:
         io.savemat(matfile, matdict)
         return self.X @ self.F @ self.X
 
+    @limited_call                       # (the step's host eigenproblems and products: _hostblas.py)
     def FockToP(self):
         """Density matrix for the current Fock matrix (scfE.py:301-462).  Returns the sorted
         orbital energies and their occupations; ``self.P`` holds the density matrix."""

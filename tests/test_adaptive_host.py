@@ -114,3 +114,32 @@ def test_bench_flop_accounting():
     assert abs(r["achieved"] - 80.0) < 1e-9 and abs(r["mfma_executed"] - 60.0) < 1e-9 and r["frac"] < r["frac_algorithmic"]
     with pytest.raises(AssertionError):
         bench.roofline_pair(8e12, 9e12, 0.1)             # more than the peak issued: the accounting is wrong
+
+
+def test_host_blas_thread_limit_is_scoped(monkeypatch):
+    """The density step limits the threads of its host BLAS / LAPACK calls (_hostblas.py) and gives the setting back:
+    inside ``limited()`` every BLAS pool runs at most host_threads() threads, afterwards what it had before."""
+    import importlib
+    tpc = pytest.importorskip("threadpoolctl")
+    from gaunegf_amd import _hostblas
+    monkeypatch.setenv("NEGF_HOST_BLAS_THREADS", "2")
+    hb = importlib.reload(_hostblas)
+    try:
+        assert hb.host_threads() == 2
+        before = {d["filepath"]: d["num_threads"] for d in tpc.threadpool_info()}
+        with hb.limited():
+            assert all(d["num_threads"] <= 2 for d in tpc.threadpool_info())
+        assert {d["filepath"]: d["num_threads"] for d in tpc.threadpool_info()} == before
+
+        @hb.limited_call
+        def inside():
+            return max(d["num_threads"] for d in tpc.threadpool_info())
+        import numpy as np
+        np.linalg.eigh(np.eye(4))                       # (make sure a BLAS is loaded)
+        assert inside() <= 2
+        monkeypatch.setenv("NEGF_HOST_BLAS_THREADS", "0")
+        hb = importlib.reload(_hostblas)
+        assert hb.host_threads() is None
+    finally:
+        monkeypatch.delenv("NEGF_HOST_BLAS_THREADS", raising=False)
+        importlib.reload(_hostblas)
