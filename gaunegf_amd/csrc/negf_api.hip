@@ -1171,8 +1171,10 @@ static int gless_core(negf_ctx* c, SigmaProvider* p, int contact, int m, const c
             {
                 ProfScope ps(c, "zgemm");
                 launch_gather_block(c->stream, n, n, g.K, nb, c->G, n2, nullptr, g.idx, Gc, n2);
-                launch_zgemm(c->stream, n, g.K, g.K, nb, Gc, g.K, n2, g.mat, g.K, g.stride, 0, X, g.K, n2);
-                launch_zgemm(c->stream, n, n, g.K, nb, X, g.K, n2, Gc, g.K, n2, 3, c->W1, n, n2);   // Hermitian result
+                // X = (Gc Gamma)^H, K x n, stored conjugate-transposed by the first product; W1 = Gc X: the second operand
+                // in the plain form (see the dense products below)
+                launch_zgemm(c->stream, n, g.K, g.K, nb, Gc, g.K, n2, g.mat, g.K, g.stride, 4, X, n, n2);
+                launch_zgemm(c->stream, n, n, g.K, nb, Gc, g.K, n2, X, n, n2, 2, c->W1, n, n2);     // Hermitian result
             }
             accumulate(c->W1, m0, nb);
             continue;
