@@ -209,7 +209,9 @@ class NEGFE:
 
         # level occupations in the Lowdin basis (scfE.py:460-468)
         D, V = np.linalg.eigh(self.X @ F @ self.X)
-        Xi = np.linalg.inv(self.X)
+        if getattr(self, "_Xi_of", None) is not self.X:                     # inv(X) of the step before, while X is the same array
+            self._Xi, self._Xi_of = np.linalg.inv(self.X), self.X
+        Xi = self._Xi
         pshift = V.conj().T @ (Xi @ P @ Xi) @ V
         self.P = np.array(P)
         occList = np.diag(np.real(pshift))
