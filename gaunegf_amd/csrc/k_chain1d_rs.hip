@@ -1,25 +1,30 @@
 // 1-D chain contact self-energy ("decimation") for n_c <= 64, register-stationary version.
 // gauNEGF/surfG1D.py:223-295 (g), :344-373 (sigma).  gfx950.
 //
-// One workgroup (256 threads, 4 waves) per (energy, contact); SEVERAL workgroups per CU.  The fixed
-// point is a chain of ~2000 dependent sweeps per workgroup, each a chain of 50 dependent pivot
-// steps, so one workgroup can never fill a CU: the kernel is built to be small enough that three
-// (n_c <= 57) or two workgroups share a CU and cover each other's latency chains.  That means ONE
-// n x n work matrix in LDS per workgroup (40.8 KB at n_c = 50) and <= 168 VGPRs:
+// A JOB is one fixed point (energy, contact); a workgroup (256 threads, 4 waves) runs one job at a time, SEVERAL
+// workgroups per CU.  The fixed point is a chain of up to 2000 dependent sweeps, each a chain of 50 dependent pivot
+// steps, so one workgroup can never fill a CU: the kernel is built to be small enough that three (n_c <= 57) or two
+// workgroups share a CU and cover each other's latency chains.  That means ONE n x n work matrix in LDS per workgroup
+// (40.8 KB at n_c = 50) and <= 168 VGPRs:
 //   * B = (E + i eta) Sb - b is not stored per workgroup at all: wave w needs only row tile w of B, as
 //     the A operand of T = B g (wave w owns row tile w of T) and, conjugated, as the B operand of
 //     M = A - T B^H (wave w owns column tile w of M); it streams those 16 x n elements from the lead
 //     matrices Sb, b (shared by all workgroups of the contact, L2-resident) a few k-steps ahead.
 //   * the iterate g is kept twice: in the work matrix at the start of a sweep (B operand of T = B g;
 //     overwritten by T, then M) and as the "old" g of the mixing step, which each lane writes and
-//     reads back for its own 16 elements only: in a second LDS matrix when two workgroups share
-//     the CU, in a lane-private global scratch record (L2-resident) when three do.
-//   * the in-place Gauss-Jordan inverse of M works on column tiles OWNED by one wave per stage:
-//     the owner reads the pivot rows it needs (the Q fragment of its column tile) into registers
-//     before it writes, so no snapshot buffer and ONE workgroup barrier per 16-column panel.
-//     Panel s+1 is factored (one wave, lane = row, DPP arg-max, pivot row through v_readlane, no
-//     LDS traffic or barrier inside) while the other waves apply panel s; the factoring wave
-//     rotates with the panel so that the SIMDs share that load.
+//     reads back for its own 13 elements only: in a second LDS matrix when two workgroups share
+//     the CU; when three do, the first slots in the unused rows of the work matrix and the rest in a
+//     lane-private global scratch record (L2-resident).
+//   * the in-place Gauss-Jordan inverse of M works on panels of 8 columns (RS_PANEL).  The wave on SIMD 0 -- the
+//     CHAIN wave (rs_wave_role: the roles follow the SIMD a wave runs on, because an FP64 matrix instruction holds
+//     its SIMD's vector issue) -- factors every panel: lane = row, DPP arg-max on the high word of |re| + |im|, the
+//     pivot row through a 128-byte LDS line, no workgroup barrier inside.  The other three waves apply the previous
+//     panel to the column tiles they OWN (the owner reads the pivot rows it needs, the Q fragment of its tile, into
+//     registers before it writes: no snapshot buffer); all four bring the next panel's columns up to date first
+//     (look-ahead).  Products and updates are three real matrix instructions per complex tile and k-step (3M).
+//   * launches with more jobs than resident slots run them ROUND ROBIN through a device-side queue (ChainRsArgs,
+//     rs_rr_pop / rs_rr_push): a persistent workgroup per slot, quanta of 100 sweeps, the iterate of a job that is
+//     set aside waits in the job's output block.
 // Per sweep
 //     T     = B g ;  M = A - T B^H          2 complex GEMMs on the FP64 matrix cores
 //     g_new = inv(M)                         blocked Gauss-Jordan, partial pivoting (izamax rule)
@@ -28,7 +33,7 @@
 // The stopping rule only needs "diff > conv" / "diff <= conv"; both are evaluated on the squares
 // (|d|^2 > conv^2 max(|g_new|^2, 1e-24)), which is the same predicate without sqrt and divide.
 //
-// Every workgroup stops on ITS OWN convergence (the reference's vmap runs all energies until the
+// Every job stops on ITS OWN convergence (the reference's vmap runs all energies until the
 // slowest lane converges; results are identical because a converged lane is frozen there).
 #include "negf_common.h"
 #include "wave_utils.h"
