@@ -253,6 +253,11 @@ def kernel_source_id(fname="k_chain1d_rs.hip"):
         return None
 
 
+# the chain kernel of the TIMED C3 steps as rocprofv3 names it: pitch class 51 (n_c = 50), three workgroups per CU, old iterate
+# partly in global scratch, the plain instantiation (the round-robin one, "..., true>", serves first evaluations)
+CHAIN_KERNEL_TIMED = "chain1d_rs_kernel<51, 3, true, false>"
+
+
 def pmc_traffic_bytes(kernel_substr, source_file="k_chain1d_rs.hip"):
     """HBM bytes per launch from a committed PMC profile (separate --pmc passes): 2 x FETCH_SIZE (gfx950 reports
     half of a wide coalesced read stream, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, both in KiB.
@@ -442,8 +447,8 @@ def worker_c3(args):
         launches_per_step = ch_launches / args.steps
         avg_chain_ms = ch_ms / ch_launches
         rl = roofline_pair(flops_chain_step / launches_per_step, mfma_chain_step / launches_per_step, avg_chain_ms * 1e-3)
-        traffic, traffic_src = pmc_traffic_bytes("chain1d_rs_kernel")
-        busy = pmc_counter("chain1d_rs_kernel", "SQ_VALU_MFMA_BUSY_CYCLES")
+        traffic, traffic_src = pmc_traffic_bytes(CHAIN_KERNEL_TIMED)
+        busy = pmc_counter(CHAIN_KERNEL_TIMED, "SQ_VALU_MFMA_BUSY_CYCLES")
         inv_rl = roofline_pair(inv_flops[0], inv_flops[1], inv_ms * 1e-3)
         line = {
             "metric": "energy-points/sec (complex128 G(E) solves)",
@@ -471,7 +476,7 @@ def worker_c3(args):
                                        "frac_algorithmic = achieved / peak (8 flop per complex multiply-add, SURVEY 8d)",
                          "mfma_busy_frac": (busy / (avg_chain_ms * 1e-3 * PEAK_CLOCK_HZ * N_SIMD)) if busy else None,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "chain1d_rs_kernel (1-D chain decimation fixed points, energy x contact; one persistent workgroup per resident slot, the fixed points round robin in quanta of 100 sweeps)",
+                         "kernel": "chain1d_rs_kernel (1-D chain decimation fixed points, energy x contact; timed steps: one workgroup per fixed point, longest first by the counts of the evaluation before; a first evaluation: persistent workgroups, the fixed points round robin in quanta of 100 sweeps)",
                          "avg_launch_ms": avg_chain_ms, "launches": ch_launches,
                          "sweeps_per_launch": sweeps_per_step / launches_per_step,
                          "flops_per_sweep": 24.0 * NC ** 3, "mfma_flops_per_sweep": per_sweep,

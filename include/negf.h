@@ -249,9 +249,11 @@ int negf_set_small_algo(negf_ctx* ctx, int algo);
  * before the first evaluation.  The kernel runs them ROUND ROBIN: one persistent workgroup per resident slot, a fixed
  * point runs `quantum` sweeps and, when others wait, goes to the back of a device-side queue with its iterate.  The
  * chip then stays full until fewer fixed points than slots are left, whatever order they were started in; results
- * do not depend on it (a fixed point is a sequence of sweeps on its own data).  quantum: < 0 = default (environment
- * NEGF_CHAIN_RR, else 100), 0 = off (every workgroup one fixed point, started longest first by the counts predicted
- * from the previous evaluation).  slots: 0 = every resident slot of the device; > 0 caps them (tests). */
+ * do not depend on it (a fixed point is a sequence of sweeps on its own data).  quantum: < 0 = default -- quanta of
+ * NEGF_CHAIN_RR (else 100) sweeps for launches whose sweep counts CANNOT be predicted (the first evaluation of a grid by
+ * a provider), and one workgroup per fixed point, started longest first by the counts predicted from the previous
+ * evaluation, for those that can (that launch is ~1 % faster when the order is good); 0 = never round robin;
+ * > 0 = always, with this quantum.  slots: 0 = every resident slot of the device; > 0 caps them (tests). */
 int negf_set_chain_round_robin(negf_ctx* ctx, int quantum, int slots);
 /* G Gamma G^H (integrate.py:81) and Tr[Gamma_L G Gamma_R G^H] (transport.py:156-157):
  * 0 = auto -- when the coupling matrices only touch the contact orbitals (CONST providers
