@@ -45,18 +45,33 @@ def host_threads():
     return _limit or None
 
 
+_controller = None
+
+
+def _blas_controller():
+    """threadpoolctl's handle on the BLAS / OpenMP pools loaded so far (looking them up walks every shared object of
+    the process, ~1 ms: done once, after numpy and scipy.linalg are in)."""
+    global _controller
+    if _controller is None:
+        try:
+            import numpy.linalg                                      # noqa: F401
+            import scipy.linalg                                      # noqa: F401
+            from threadpoolctl import ThreadpoolController
+            _controller = ThreadpoolController()
+        except Exception:
+            _controller = False
+    return _controller or None
+
+
 @contextlib.contextmanager
 def limited():
     """``with limited():`` -- host BLAS calls inside run with host_threads() threads."""
     n = host_threads()
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:
-        threadpool_limits = None
-    if n is None or threadpool_limits is None:
+    ctl = _blas_controller() if n is not None else None
+    if ctl is None:
         yield
         return
-    with threadpool_limits(limits=n):
+    with ctl.limit(limits=n):
         yield
 
 
