@@ -15,7 +15,21 @@ vectors captured from the reference's own functions (tests/golden/).
     broadening_grid         densityComplexN :730-742      GrInt           (added to the contour)
 """
 import numpy as np
-from scipy.special import roots_legendre
+from scipy.special import roots_legendre as _scipy_roots_legendre
+import functools
+
+
+@functools.lru_cache(maxsize=64)
+def _legendre_nodes(N):
+    x, w = _scipy_roots_legendre(N)
+    x.setflags(write=False); w.setflags(write=False)
+    return x, w
+
+
+def roots_legendre(N):
+    """scipy.special.roots_legendre, the nodes of each order kept (an SCF run asks for the same few orders in every
+    density step: 9 calls, 2 ms of an N = 60 step); read-only arrays, the same bits."""
+    return _legendre_nodes(int(N))
 
 from .config import (TEMPERATURE, ADAPTIVE_INTEGRATION_TOL, N_KT, MAX_CYCLES, MAX_GRID_POINTS)
 from .integrate import GrInt, GrLessInt, GrIntSegments, GrLessIntSegments
