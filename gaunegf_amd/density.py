@@ -139,7 +139,7 @@ def _adaptive_ant_steps(levels, tol, budget, direct=None):
                 print(f"N={N}, nested-weight ratio ~ {ratio:.3f}, maxDP={maxDP:.3e}")
                 print(f"Direct Calculation: N={N}, maxDP={np.max(np.abs(full - P)):.3e}, "
                       f"maxDiff={np.max(np.abs(full - new_P)):.3e}")
-            P = new_P.copy()
+            P = new_P                                   # (a fresh array every level: P * ratio allocates; no copy needed)
             if maxDP < tol:
                 print(f'Adaptive integration converged to {maxDP:.3e} in {N} points.')
                 return new_P
