@@ -143,3 +143,20 @@ def test_host_blas_thread_limit_is_scoped(monkeypatch):
     finally:
         monkeypatch.delenv("NEGF_HOST_BLAS_THREADS", raising=False)
         importlib.reload(_hostblas)
+
+
+def test_lowest_orbital_energy_routes():
+    """calcEmin starts 5 eV below min Re eig(inv(S) F) (density.py:822).  Small or non-Hermitian systems take the
+    reference's non-symmetric eigenproblem, bit for bit; a Hermitian system of >= 256 orbitals takes the lowest
+    generalised eigenvalue of (F, S) -- the same number to rounding."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import random_system
+    F, S = random_system(120, 3)
+    assert D._lowest_orbital_energy(F, S) == min(D._orbital_energies(F, S))
+    F, S = random_system(300, 4)
+    ref = min(D._orbital_energies(F, S))
+    assert abs(D._lowest_orbital_energy(F, S) - ref) < 1e-11 * abs(ref)
+    Fn = F.copy(); Fn[0, 1] += 1e-3                              # not Hermitian any more: the reference's route
+    assert D._lowest_orbital_energy(Fn, S) == min(D._orbital_energies(Fn, S))
+    Sbad = S.copy(); Sbad[np.arange(300), np.arange(300)] -= 10.0   # Hermitian but not positive definite: falls back
+    assert D._lowest_orbital_energy(F, Sbad) == min(D._orbital_energies(F, Sbad))
