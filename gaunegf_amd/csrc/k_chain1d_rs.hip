@@ -1092,7 +1092,8 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
         // evaluation of a grid by this provider: 725 against 800 ms in launch order on the C3 grid): one persistent
         // workgroup per resident slot then.  With a predicted order the plain launch, longest job first, is the faster
         // one (718 against 726 ms: its kernel carries no job loop), so the round robin is left to the launches without
-        // an order -- unless the caller set the quantum himself (negf_set_chain_round_robin: tests, A/B).
+        // an order or with one predicted from too few points (order_trusted) -- unless the caller set the quantum
+        // himself (negf_set_chain_round_robin: tests, A/B).
         const int jobs = n_contacts * nb, slots = rr_slots > 0 ? std::min(rr_slots, occ * n_cus) : occ * n_cus;
         const bool rr = RS_RR && aa.rr_quantum > 0 && jobs > slots && (aa.order == nullptr || rr_forced);
         if (rr) {
@@ -1120,7 +1121,7 @@ void chain1d_rs_launch(hipStream_t st, ChainRsArgs a, int n_max, int n_contacts,
 
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
                         const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
-                        cplx* gcache, int gc_mode, int rr_quantum, int rr_slots)
+                        cplx* gcache, int gc_mode, int rr_quantum, int rr_slots, bool order_trusted)
 {
     ChainRsArgs a;
     a.order = order;
@@ -1170,7 +1171,7 @@ void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc,
         const int strip_base = n <= 16 ? -1 : n <= 19 ? 16 : (n > 32 && n <= 35) ? 32 : (n > 48 && n <= 51) ? 48 : -1;
         if (strip_base > 0 && n_min <= strip_base) n = strip_base == 16 ? 25 : strip_base == 32 ? 41 : 57;
     }
-#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n_max, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env, rr_slots, rr_cap, rr_quantum > 0)
+#define RS_CASE(PP) chain1d_rs_launch<PP>(st, a, n_max, p.n_contacts, nb, E, blk, iters, conv, gold_scratch, occ_env, rr_slots, rr_cap, rr_quantum > 0 || !order_trusted)
 #ifdef RS_FAST_BUILD
     if (n <= 16) RS_CASE(17); else RS_CASE(51);
 #else

@@ -436,7 +436,8 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
             // (k_chain1d_rs.hip) and only takes the order as the initial content of its queue.
             const bool can_order = p->force_iters < 0 && iters && chain1d_order_supported(jobs);
             const int* order = nullptr;
-            if (can_order) {
+            bool order_trusted = true;                      // a prediction from fewer than half as many energies as this
+            if (can_order) {                                //  launch evaluates is a guess: such a launch runs round robin
                 if (jobs > p->order_cap) {
                     NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
                     dev_free(p->d_order); p->order_cap = 0;
@@ -450,6 +451,7 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                     std::swap(p->prev_cap, p->cur_cap);
                     p->prev_n = p->cur_n; p->cur_n = 0;
                 }
+                order_trusted = 2 * (p->prev_n > 0 ? p->prev_n : p->cur_n) >= nb;
                 if (p->prev_n > 0) {
                     launch_chain1d_predict_order(c->stream, p->d_prevE, p->d_prev_iters, p->prev_n, p->n_contacts, E, nb, p->d_order);
                     order = p->d_order;
@@ -460,7 +462,7 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
                 }
             }
             launch_chain1d_lds(c->stream, *p, p->d_nc, p->d_blk_off, nb, E, c->d_blk, iters, conv, c->d_scratch, order,
-                               ent ? ent->d_g : nullptr, 1, c->chain_rr_quantum, c->chain_rr_slots);
+                               ent ? ent->d_g : nullptr, 1, c->chain_rr_quantum, c->chain_rr_slots, order_trusted);
             if (ent) {
                 NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_it, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
                 NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_cv, conv, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));

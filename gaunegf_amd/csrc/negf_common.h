@@ -314,10 +314,12 @@ size_t chain1d_lds_scratch_elems(int nc_max, int n_contacts, int nb, int max_swe
 // order: launch slot -> job (energy * n_contacts + contact) or null for launch order
 // gcache / gc_mode: see ChainGEntry -- 0 no cache, 1 store the final iterates, 2 load them and only form Sigma
 // rr_quantum / rr_slots: round-robin execution of a launch with more jobs than resident slots (ChainRsArgs; < 0 / 0:
-// the defaults -- NEGF_CHAIN_RR or 100 sweeps, every slot of the device)
+// the defaults -- NEGF_CHAIN_RR or 100 sweeps, every slot of the device); order_trusted = false: the order is a
+// guess (predicted from few points), a launch with more jobs than slots runs round robin all the same
 void launch_chain1d_lds(hipStream_t st, const SigmaProvider& p, const int* d_nc, const int* d_blk_off, int nb,
                         const cplx* E, cplx* blk, int* iters, int* conv, cplx* gold_scratch, const int* order,
-                        cplx* gcache = nullptr, int gc_mode = 0, int rr_quantum = -1, int rr_slots = 0);
+                        cplx* gcache = nullptr, int gc_mode = 0, int rr_quantum = -1, int rr_slots = 0,
+                        bool order_trusted = true);
 // order[0..count) = jobs by decreasing sweep count predicted from the previous evaluation (k_chain1d_order.hip)
 bool chain1d_order_supported(int count);
 void launch_chain1d_predict_order(hipStream_t st, const cplx* prevE, const int* prev_iters, int prev_n, int n_contacts,
