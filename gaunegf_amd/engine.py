@@ -133,8 +133,8 @@ class Engine:
         """Make F, S the resident system.  The library keeps the last two systems on the device and recognises them
         bitwise (negf_set_system): calls that repeat a system, or alternate between two -- the spin blocks of a
         blockdiag(alpha, beta) Fock matrix -- upload nothing."""
-        F = _c128(F)
-        S = _c128(S)
+        F = self._c128_cached(F)
+        S = self._c128_cached(S)
         assert F.shape == S.shape, "F and S must have the same shape"
         assert F.ndim == 2 and F.shape[0] == F.shape[1], "F and S must be square matrices"
         n_changed = F.shape[0] != self.n
@@ -143,6 +143,25 @@ class Engine:
         if n_changed:
             self.generation = getattr(self, "generation", 0) + 1   # provider handles died
         return True
+
+    def _c128_cached(self, a):
+        """complex128 C-contiguous form of a system matrix.  An SCF step hands the same REAL F and S to every one of its
+        ~30 integrals; converting 2 x 5 MB to complex at N = 800 each time is 2 ms per call.  The conversions of the last
+        four matrices are kept together with a snapshot of their source: the same array object with the same content
+        (compared element by element -- a caller may have changed it in place) gets its conversion back."""
+        a = np.asarray(a)
+        if a.dtype == np.complex128 and a.flags.c_contiguous:
+            return a                                              # (nothing to convert)
+        cache = self.__dict__.setdefault("_sys_conv", [])
+        for k, (src, snap, conv) in enumerate(cache):
+            if src is a and snap.shape == a.shape and snap.dtype == a.dtype and np.array_equal(a, snap):
+                cache.append(cache.pop(k))
+                return conv
+        conv = _c128(a)
+        if a.size >= 128 * 128:                                   # (below that the conversion costs less than the comparison's overhead)
+            cache.append((a, a.copy(), conv))
+            del cache[:-4]
+        return conv
 
     # ------------------------------------------------------------ providers
     def sigma_const(self, sigmas):

@@ -160,3 +160,25 @@ def test_lowest_orbital_energy_routes():
     assert D._lowest_orbital_energy(Fn, S) == min(D._orbital_energies(Fn, S))
     Sbad = S.copy(); Sbad[np.arange(300), np.arange(300)] -= 10.0   # Hermitian but not positive definite: falls back
     assert D._lowest_orbital_energy(F, Sbad) == min(D._orbital_energies(F, Sbad))
+
+
+def test_engine_keeps_conversions_of_unchanged_system_matrices():
+    """Engine._c128_cached: the same real array with the same content gets its complex conversion back (same object);
+    a change in place, another array or a complex contiguous input are converted / passed through afresh."""
+    from gaunegf_amd.engine import Engine
+    eng = object.__new__(Engine)                         # (no context: only the host-side helper is exercised)
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((160, 160))
+    c1 = eng._c128_cached(A)
+    assert c1.dtype == np.complex128 and np.array_equal(c1, A)
+    assert eng._c128_cached(A) is c1
+    A[3, 4] += 1.0                                       # changed in place: a new conversion with the new content
+    c2 = eng._c128_cached(A)
+    assert c2 is not c1 and c2[3, 4] == A[3, 4]
+    B = A.copy()
+    assert eng._c128_cached(B) is not c2 and eng._c128_cached(A) is c2
+    Z = A.astype(np.complex128)
+    assert eng._c128_cached(Z) is Z
+    for k in range(6):                                   # the cache holds four matrices
+        eng._c128_cached(rng.standard_normal((130, 130)))
+    assert len(eng._sys_conv) == 4
