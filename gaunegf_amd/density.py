@@ -118,6 +118,7 @@ def _adaptive_ant_steps(levels, tol, budget, direct=None):
     whatever company.  ``direct(N)`` (debug only) evaluates the whole level-N rule for the reference's debug prints."""
     ahead = {}
     P = new_P = None
+    bufs = mag = None
     N = 2
     maxDP = 1e10
     for i, (N, x_new, w_new, ratio) in enumerate(levels):
@@ -131,9 +132,24 @@ def _adaptive_ant_steps(levels, tol, budget, direct=None):
         if ratio is None:
             P = ahead.pop(i)
         else:
-            new_P = P * ratio
-            new_P += ahead.pop(i)
-            maxDP = np.max(np.abs(new_P - P))
+            # (the same operations as new_P = P * ratio; new_P += value; max|new_P - P|, written into work arrays that
+            #  live as long as this refinement: a fresh 10-MB array per operation and level is page faults, not arithmetic)
+            inc = ahead.pop(i)
+            if np.ndim(P) == 2 and np.shape(inc) == np.shape(P):
+                if bufs is None:
+                    dt = np.result_type(P, inc, type(ratio))
+                    bufs = [np.empty(np.shape(P), dtype=dt) for _ in range(3)]
+                    mag = np.empty(np.shape(P), dtype=np.abs(np.zeros(1, dtype=dt)).dtype)
+                new_P = bufs[0] if P is not bufs[0] else bufs[1]
+                np.multiply(P, ratio, out=new_P)
+                new_P += inc
+                np.subtract(new_P, P, out=bufs[2])
+                np.abs(bufs[2], out=mag)
+                maxDP = np.max(mag)
+            else:
+                new_P = P * ratio
+                new_P += inc
+                maxDP = np.max(np.abs(new_P - P))
             if direct is not None:
                 full = direct(N)
                 print(f"N={N}, nested-weight ratio ~ {ratio:.3f}, maxDP={maxDP:.3e}")
