@@ -158,7 +158,7 @@ class Engine:
                 cache.append(cache.pop(k))
                 return conv
         conv = _c128(a)
-        if a.size >= 128 * 128:                                   # (below that the conversion costs less than the comparison's overhead)
+        if 128 * 128 <= a.size and a.nbytes <= (64 << 20):        # (small: the conversion costs less than the comparison; large: not worth the host memory)
             cache.append((a, a.copy(), conv))
             del cache[:-4]
         return conv
