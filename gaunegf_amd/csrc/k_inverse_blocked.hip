@@ -1090,6 +1090,8 @@ __global__ __launch_bounds__(LA_NW * 64, LA_NW <= 6 ? 3 : 1) void gj_window_la_k
     if (tid == 0 && bad_sh != 0 && info[blockIdx.x] == 0) info[blockIdx.x] = bad_sh;
 }
 
+#include "gj_strip.h"
+
 // ---- Column-block big update.  A workgroup (256 threads, 4 waves; TWO per CU, which run their barriers and
 // operand waits independently of each other) OWNS a block of 64 columns outside the window and applies the window
 // to all of its rows:
@@ -1427,7 +1429,7 @@ __global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __re
 }
 
 template <int NBI, int RPT>
-void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp)
+void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp, int win_mode)
 {
     const size_t smem = (size_t)(2 * PW * NBI + 2 * NBI * WIN) * sizeof(cplx);      // candidate rows + Q of two sub-panels
     auto kern = gj_window_kernel<NBI, RPT>;
@@ -1445,6 +1447,21 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     }
     static int winla = -1;
     if (winla < 0) { const char* e = getenv("NEGF_GJ_WINLA"); winla = e ? atoi(e) : 1; }
+    // Which window kernel (win_mode 0 = auto, 1 = strip wherever an instantiation serves n, 2 = team kernels only;
+    // NEGF_GJ_STRIP = 0 / 1 sets the auto rule's answer for A/B runs).  Measured on MI355X, inverse ms per 1000 matrices,
+    // strip / team: n = 256 4.01 / 5.26 (single-workgroup kernel), 300 7.06 / 7.53, 400 13.8 / 14.6, 500 22.3 / 24.5 --
+    // the strip kernel moves 3.3 MB per window and matrix instead of 4.9, and both run at the ~4.3 TB/s this access
+    // pattern gets out of the memory system; n = 650 56.7 / 54.1, 800 85.9 / 83.6, 1000 146.5 / 147.2 (the 8-wave, one-per-CU
+    // form: no gain), and small stream groups (a lean 4-wave workgroup has a longer chain per matrix than the 12-wave
+    // look-ahead kernel): 250 x n = 500 in four groups 6.57 / 6.11, 64 x n = 500 3.32 / 2.65.
+    static int strip_env = -2;
+    if (strip_env == -2) { const char* e = getenv("NEGF_GJ_STRIP"); strip_env = e ? atoi(e) : -1; }
+    static int strip_min = -1;           // matrices per stream group from which the auto rule takes the strip kernel (257 <= n <= 512)
+    if (strip_min < 0) { const char* e = getenv("NEGF_GJ_STRIP_MIN"); strip_min = e ? atoi(e) : 192; }
+    static int strip_cfg = -1;           // 0: the measured choice per size; 1: n <= 512 fat (8 waves x 1 row, sub-windows of 32); 3: n <= 256 with sub-windows of 16; 4: n <= 512 lean with two chunks in flight
+    if (strip_cfg < 0) { const char* e = getenv("NEGF_GJ_STRIP_CFG"); strip_cfg = e ? atoi(e) : 0; }
+    static int strip_dbg = -1;           // timing ablations of the strip kernel (wrong results)
+    if (strip_dbg < 0) { const char* e = getenv("NEGF_GJ_STRIP_DBG"); strip_dbg = e ? atoi(e) : 0; }
     static int pair = -1;                // windows in pairs (one pass over the other column blocks per pair); 0: one by one
     if (pair < 0) { const char* e = getenv("NEGF_GJ_PAIR"); pair = e ? atoi(e) : 1; }
     static long pair_min = -1, fat_max = -1, fat_total_max = -1;
@@ -1460,6 +1477,22 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         hipLaunchKernelGGL(gj_state_init_kernel, dim3(count), dim3(256), 0, s, n, pg, ig);
         auto window = [&](int c0, int cw) {
             unsigned long long* stp = (c0 == WIN && first == 0) ? d_stamps : (unsigned long long*)nullptr;
+            const bool strip = NBI == 16 && (win_mode == 1 || (win_mode == 0 && (strip_env >= 0 ? strip_env != 0 : (n <= 256 || (n <= 512 && count >= strip_min)))));
+            if (strip) {
+                if (n <= 256 && strip_cfg != 3)
+                    hipLaunchKernelGGL((gj_window_strip_kernel<1, 32, 4, 2, 4>), dim3(count), dim3(256), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
+                else if (n <= 256)
+                    hipLaunchKernelGGL((gj_window_strip_kernel<1, 16, 4, 3, 4>), dim3(count), dim3(256), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
+                else if (n <= 512 && strip_cfg == 1)
+                    hipLaunchKernelGGL((gj_window_strip_kernel<1, 32, 8, 1, 4>), dim3(count), dim3(512), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
+                else if (n <= 512 && strip_cfg == 4)     // two chunks in flight: 72 spilled registers, 23.3 ms against 22.6 (1000 x n = 500)
+                    hipLaunchKernelGGL((gj_window_strip_kernel<2, 16, 4, 2, 2>), dim3(count), dim3(256), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
+                else if (n <= 512)
+                    hipLaunchKernelGGL((gj_window_strip_kernel<2, 16, 4, 2, 1>), dim3(count), dim3(256), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
+                else
+                    hipLaunchKernelGGL((gj_window_strip_kernel<2, 16, 8, 1, 2>), dim3(count), dim3(512), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
+                return;
+            }
             if (NBI == 16 && RPT == 1 && winla && n <= 256)
                 hipLaunchKernelGGL((gj_window_la_kernel<16, 4, 6>), dim3(count), dim3(6 * 64), smem, s, n, Ag, stride, pg, ig, c0, cw, stp);
             else if (NBI == 16 && RPT == 1 && winla)
@@ -1555,6 +1588,15 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         unsigned long long h[64];
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         auto us = [&](int i) { return (double)(h[i] - h[0]) / 100.0; };
+        if (NBI == 16 && (win_mode == 1 || (win_mode == 0 && strip_env != 0 && n <= 512))) {
+            fprintf(stderr, "[gj strip stamps] n=%d window 1, workgroup 0 (us since the window's start):", n);
+            for (int sp = 0; sp < 4; ++sp)
+                fprintf(stderr, " | sub %d: top %.1f loaded %.1f forward %.1f factored %.1f stored %.1f staged %.1f backward %.1f", sp,
+                        us(8 * sp), us(8 * sp + 1), us(8 * sp + 2), us(8 * sp + 3), us(8 * sp + 4), sp ? us(8 * sp + 5) : 0.0, us(8 * sp + 6));
+            fprintf(stderr, "\n[gj strip stamps] sub-window 1, column 4 (shader cycles from the arrival at the barrier): barrier passed %lld, winner known %lld, reciprocal %lld, strip updated %lld, published %lld; next arrival %lld\n",
+                    (long long)(h[41] - h[40]), (long long)(h[42] - h[40]), (long long)(h[43] - h[40]), (long long)(h[44] - h[40]), (long long)(h[45] - h[40]), (long long)(h[45] - h[40]));
+            return;
+        }
         if (NBI == 16 && RPT == 1 && winla) {
             fprintf(stderr, "[gj window-la stamps] n=%d window 1, workgroup 0 (us):", n);
             for (int sp = 0; sp < 4; ++sp)
@@ -1591,26 +1633,28 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // In-place reduction of A with B as scratch; the inverses are gathered into B.
 // piv: [nb][2][n] ints of pivot bookkeeping (used by the large-matrix path).
 // Returns true: the result is in B.
-bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* side)
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* side, int win_mode)
 {
     // single-workgroup kernel up to 256 rows (its 32-column panel configuration); above, the windowed
     // path with 16-column sub-panels is faster (measured on MI355X, ms per 1000 matrices: n = 260 9.3 vs
     // 9.1, 300 13.3 vs 11.1, 340 20.5 vs 17.3, 370 28.5 vs 20.1); NEGF_GJ_LARGE_MIN moves the switch-over
+    // (round 5: with the strip window kernel the windowed path wins from n = 209 on -- ms per 1000 matrices, windowed /
+    // single workgroup: n = 192 2.45 / 2.58 but 200 3.01 / 3.01 and 208 3.08 / 3.08 (a ragged fourth window), 224 3.33 / 3.56,
+    // 240 3.70 / 4.49, 256 4.01 / 5.26)
     static int large_min = -1;
-    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 257; }
-    if (n < large_min)
-    switch (gj_pick(n)) {
-    case 1: gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true;
-    default: break;
-    }
+    if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 209; }
+    // win_mode 1 (tests, A/B) takes the windowed path with the strip kernel wherever it exists (64 <= n), win_mode 2 the
+    // pre-strip configuration (single workgroup up to 256, team window kernels above)
+    const bool single_wg = win_mode == 1 ? n < 64 : win_mode == 2 ? n <= 256 : n < large_min;
+    if (single_wg && gj_pick(n) == 1) { gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true; }
     // sub-panels of 16 columns up to n = 1024 (measured on MI355X, 1000 matrices: n = 500 46.2 -> 41.1 ms,
     // n = 1000 296 -> 257 ms against sub-panels of 8: half as many passes over the 64-column window)
     switch (gj_large_pick(n)) {
-    case 1: gj_large_launch<16, 2>(st, n, nb, A, B, stride, piv, info, side); return true;
-    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info, side); return true;
-    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info, side); return true;
-    case 4: gj_large_launch<16, 1>(st, n, nb, A, B, stride, piv, info, side); return true;
-    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info, side); return true;
+    case 1: gj_large_launch<16, 2>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
+    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
+    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
+    case 4: gj_large_launch<16, 1>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
+    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
     default: return false;
     }
 }

@@ -374,10 +374,12 @@ int run_inverse(negf_ctx* c, int nb, int* info)
     ProfScope ps(c, "inverse");
     int algo = c->inverse_algo;
     if (algo == 0) algo = inverse_blocked_supported(c->n) ? 2 : 1;
+    const int win_mode = algo == 3 ? 1 : algo == 4 ? 2 : 0;      // 3 / 4: the blocked path with the window kernel chosen
+    if (algo > 2) algo = 2;
     bool in_b = false;
     if (algo == 2) {
         // false: no blocked kernel serves this n (nothing was launched) -> the unblocked kernel
-        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info, &c->gj_side);
+        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info, &c->gj_side, win_mode);
         if (!in_b) algo = 1;
     }
     if (algo == 1 && !launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info)) return NEGF_EINVAL;
@@ -774,7 +776,7 @@ int negf_get_batch(negf_ctx* c) { return c ? c->batch : 0; }
 
 int negf_set_inverse_algo(negf_ctx* c, int algo)
 {
-    if (!c || algo < 0 || algo > 2) return NEGF_EINVAL;
+    if (!c || algo < 0 || algo > 4) return NEGF_EINVAL;
     c->inverse_algo = algo;
     return NEGF_OK;
 }

@@ -261,8 +261,10 @@ void launch_assemble(hipStream_t st, int n, int nb, const cplx* E, const cplx* S
 bool launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info);
 // out-of-place ping-pong between A and B (both [nb][stride]); returns true when the
 // inverses end up in B, false when in A
+// win_mode: 0 = the measured choice of window kernel per size and batch, 1 = the strip window kernel (gj_strip.h)
+// wherever it exists, 2 = the pre-strip kernels (negf_set_inverse_algo 3 / 4)
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info,
-                            GjSideStreams* side = nullptr);
+                            GjSideStreams* side = nullptr, int win_mode = 0);
 bool inverse_blocked_supported(int n);
 
 // acc += sum_b w[b] * X[b]   (fixed summation order, deterministic); `part` is scratch of

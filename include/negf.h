@@ -237,7 +237,9 @@ int negf_profile_read(negf_ctx* ctx, const char* family, double* total_ms, int* 
  * the second may be divided by the FP64 MFMA peak and called utilisation.  Families: "inverse", "zgemm". */
 int negf_profile_read_flops(negf_ctx* ctx, const char* family, double* flops_algorithmic, double* flops_mfma_issued);
 /* choose the inverse kernel: 0 = auto, 1 = unblocked Gauss-Jordan (any n),
- * 2 = blocked Gauss-Jordan with FP64 MFMA trailing updates */
+ * 2 = blocked Gauss-Jordan with FP64 MFMA trailing updates (window kernel by size and batch),
+ * 3 = the same with the register-strip window kernel wherever it exists (64 <= n <= 1024; tests, A/B),
+ * 4 = the same with the team window kernels / the single-workgroup kernel only (the round-4 configuration) */
 int negf_set_inverse_algo(negf_ctx* ctx, int algo);
 /* systems of n <= 96 orbitals: 0 = auto -- with negf_set_inverse_algo(0), E S - F - Sigma is assembled, inverted and
  * (GrInt) accumulated in ONE kernel with the matrix held in the registers of a compute unit (no n x n work area in

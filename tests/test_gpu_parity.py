@@ -104,6 +104,64 @@ def test_blocked_inverses_random_shapes(engine):
             assert np.linalg.norm(G[k] @ A - np.eye(n)) / np.sqrt(n) < 1e-9, (n, m, k)
 
 
+@pytest.mark.parametrize("N,M,algo", [(n, m, a) for a in (3, 4) for n, m in
+                                      ((64, 5), (100, 9), (209, 13), (256, 7), (300, 6), (333, 8), (449, 17), (512, 3), (513, 2),
+                                       (650, 9), (1024, 2))])
+def test_window_kernels_by_force(engine, N, M, algo):
+    """Both window-kernel families at every size class whatever the auto rule picks for the batch
+    (negf_set_inverse_algo 3: the register-strip kernel of gj_strip.h -- n <= 256 with sub-windows of 32, 257 ... 512 the
+    lean two-rows-per-lane form, above the eight-wave form; 4: the team kernels / the single-workgroup kernel): ragged
+    last windows (n = 100: 36 columns, 209: 17, 333: 13, 449: 1, 513: 1 -- a last sub-window narrower than a chunk of
+    four), rows that end inside a wave, inside a slab, on the slab boundary (256, 512, 1024).  Oracle on a sample,
+    the residual on every matrix."""
+    from gaunegf_amd.integrate import GrBatch
+    F, S, g_dev, g_ref = _const_provider(N, 900 + N, nc=min(20, N // 4))
+    E = np.linspace(-2.5, 2.5, M) + 0.02j
+    engine.set_inverse_algo(algo)
+    try:
+        G = GrBatch(F, S, g_dev, E)
+    finally:
+        engine.set_inverse_algo(0)
+    for k in (0, M - 1):
+        ref = oracle.gr_batch(F, S, g_ref, E[k:k + 1])[0]
+        assert rel_fro(G[k], ref) < TOL, (N, M, algo, k, rel_fro(G[k], ref))
+    for k in range(M):
+        A = E[k] * S - F - np.asarray(g_ref.sigmaTot(E[k]))
+        assert np.linalg.norm(G[k] @ A - np.eye(N)) / np.sqrt(N) < 1e-9, (N, M, algo, k)
+
+
+@pytest.mark.parametrize("N,algo", [(n, a) for n in (100, 240, 300, 400, 700) for a in (3, 4)])
+def test_singular_and_nan_matrices_by_window_kernel(engine, N, algo):
+    """The singular / NaN reporting of test_singular_and_nan_matrices_in_blocked_kernels through each window-kernel family."""
+    from gaunegf_amd.integrate import GrBatch
+
+    class Probe:
+        def __init__(self, bad): self.bad = bad
+        def sigmaTot(self, E):
+            z = np.zeros((N, N), dtype=complex)
+            if self.bad == "nan" and abs(E - 1.0) < 1e-12:
+                z[:, 3] = np.nan
+            return z
+        def sigma(self, E, i): return np.zeros((N, N), dtype=complex)
+
+    S = np.eye(N)
+    Fz, _ = random_system(N, 7)
+    E = np.array([0.5 + 0.1j, 1.0 + 0j, 2.0 + 0.1j])
+    engine.set_inverse_algo(algo)
+    try:
+        for bad, F in (("singular", np.eye(N)), ("nan", Fz)):
+            with warnings.catch_warnings(record=True):
+                warnings.simplefilter("always")
+                G = GrBatch(F, S, Probe(bad), E)
+            assert np.all(np.isnan(G[1])), bad
+            assert engine.last_info[1] != 0 and engine.last_info[0] == 0 and engine.last_info[2] == 0
+            for k in (0, 2):
+                ref = np.linalg.inv(E[k] * S - F)
+                assert rel_fro(G[k], ref) < TOL, (bad, k)
+    finally:
+        engine.set_inverse_algo(0)
+
+
 @pytest.mark.parametrize("N,M", [(300, 480), (449, 640)])
 def test_windowed_inverse_large_batches(engine, N, M):
     """Batches large enough for the throughput configuration of the windowed inverse: four stream groups of >= 120
