@@ -1428,6 +1428,8 @@ __global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __re
     if (threadIdx.x == 0) info[blockIdx.x] = 0;
 }
 
+double g_gj_vector_flops = 0;            // 3M-equivalent flops of the last launch that ran as VECTOR work (strip window kernels)
+
 template <int NBI, int RPT>
 void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp, int win_mode)
 {
@@ -1477,8 +1479,10 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         hipLaunchKernelGGL(gj_state_init_kernel, dim3(count), dim3(256), 0, s, n, pg, ig);
         auto window = [&](int c0, int cw) {
             unsigned long long* stp = (c0 == WIN && first == 0) ? d_stamps : (unsigned long long*)nullptr;
+            // (matrix-core flop accounting: with the strip kernel the window's own 6 n cw^2 are vector work)
             const bool strip = NBI == 16 && (win_mode == 1 || (win_mode == 0 && (strip_env >= 0 ? strip_env != 0 : (n <= 256 || (n <= 512 && count >= strip_min)))));
             if (strip) {
+                g_gj_vector_flops += 6.0 * (double)((n + 15) & ~15) * cw * (double)cw * count;
                 if (n <= 256 && strip_cfg != 3)
                     hipLaunchKernelGGL((gj_window_strip_kernel<1, 32, 4, 2, 4>), dim3(count), dim3(256), 0, s, n, Ag, Bg, stride, pg, ig, c0, cw, stp, strip_dbg);
                 else if (n <= 256)
@@ -1633,8 +1637,11 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // In-place reduction of A with B as scratch; the inverses are gathered into B.
 // piv: [nb][2][n] ints of pivot bookkeeping (used by the large-matrix path).
 // Returns true: the result is in B.
+double inverse_blocked_vector_flops() { return g_gj_vector_flops; }
+
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* side, int win_mode)
 {
+    g_gj_vector_flops = 0;
     // single-workgroup kernel up to 256 rows (its 32-column panel configuration); above, the windowed
     // path with 16-column sub-panels is faster (measured on MI355X, ms per 1000 matrices: n = 260 9.3 vs
     // 9.1, 300 13.3 vs 11.1, 340 20.5 vs 17.3, 370 28.5 vs 20.1); NEGF_GJ_LARGE_MIN moves the switch-over

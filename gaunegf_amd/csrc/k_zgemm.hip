@@ -452,7 +452,11 @@ void launch_zgemm(hipStream_t st, int M, int N, int K, int nb,
             tiles = 0;                                      //  blocks are of similar size)
             for (int tj = 0; tj < (int)tn; ++tj) tiles += std::min<double>(tm, bt * (tj / bt + 1));
         }
-        negf_count_flops(8.0 * M * (double)N * K * nb, zgemm_algo() == 1 ? 0.0 : 3.0 * 2.0 * 256.0 * kp * tiles * nb);
+        // ALGORITHMIC flops of a Hermitian product: the symmetry-exploiting count -- the elements on and above the diagonal,
+        // 8 K flops each (N (N + 1) / 2 of the N^2: the mirrored half is a copy, not arithmetic) -- so that no fraction
+        // derived from it can exceed the peak (round 4 charged 8 M N K and reported 1.30 "of peak" for C5's products)
+        const double alg = (opB & 2) ? 8.0 * K * 0.5 * N * ((double)N + 1.0) * nb : 8.0 * M * (double)N * K * nb;
+        negf_count_flops(alg, zgemm_algo() == 1 ? 0.0 : 3.0 * 2.0 * 256.0 * kp * tiles * nb);
     }
     if (zgemm_algo() == 1) {
         dim3 grid((N + 31) / 32, (M + 31) / 32, nb);

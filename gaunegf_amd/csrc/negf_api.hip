@@ -51,13 +51,22 @@ namespace {
 
 int wait_stream(negf_ctx* c);
 
+// every live context of the process: when an allocation fails, the g(E) caches (up to 8 GB each, reusable results, not
+// state) are dropped before the allocation is given up
+std::vector<negf_ctx*>& live_contexts() { static std::vector<negf_ctx*> v; return v; }
+bool drop_gcaches();
+
 template <typename T>
-int dev_alloc(T** p, size_t count)
+int dev_alloc(T** p, size_t count, bool may_drop_caches = true /* false: the allocation IS a cache entry */)
 {
     *p = nullptr;
     if (count == 0) return NEGF_OK;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
-    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return NEGF_ENOMEM; }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (may_drop_caches && drop_gcaches()) e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));      // once more without the caches
+        if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return NEGF_ENOMEM; }
+    }
     return NEGF_OK;
 }
 template <typename T>
@@ -118,6 +127,16 @@ void free_gcache(negf_ctx* c)
 {
     for (auto& e : c->gcache) free_gentry(e);
     c->gcache.clear();
+}
+
+// true: something was freed.  (Entries in use by a launch in flight are freed by hipFree after that launch: hipFree
+// synchronises the device.)
+bool drop_gcaches()
+{
+    bool any = false;
+    for (negf_ctx* c : live_contexts())
+        if (!c->gcache.empty() && !c->gcache_pinned) { free_gcache(c); any = true; }
+    return any;
 }
 
 // 64-bit mixing hash over the 8-byte words of a buffer (a filter in front of the bitwise comparisons of the g(E) cache)
@@ -193,7 +212,7 @@ ChainGEntry* gcache_lookup(negf_ctx* c, const SigmaProvider* p, const cplx* Eh, 
     }
     if (g_elems > v->g_cap || it_elems > v->it_cap) {
         free_gentry(*v);
-        if (dev_alloc(&v->d_g, g_elems) || dev_alloc(&v->d_it, it_elems) || dev_alloc(&v->d_cv, it_elems)) { free_gentry(*v); return nullptr; }
+        if (dev_alloc(&v->d_g, g_elems, false) || dev_alloc(&v->d_it, it_elems, false) || dev_alloc(&v->d_cv, it_elems, false)) { free_gentry(*v); return nullptr; }
         v->g_cap = g_elems; v->it_cap = it_elems;
     }
     v->nc = p->nc; v->lead = p->h_lead; v->lead_hash = p->lead_hash; v->E_hash = eh;
@@ -387,7 +406,7 @@ int run_inverse(negf_ctx* c, int nb, int* info)
     {   // 8 n^3 algorithmic; the blocked kernels run every rank-NB update on the matrix cores in 3M form over
         // 16-granular tiles (the pivot steps themselves are vector work), the unblocked kernel none of it
         const double n = c->n, np = (double)((c->n + 15) & ~15);
-        negf_count_flops(8.0 * n * n * n * nb, algo == 2 ? 6.0 * n * np * np * nb : 0.0);
+        negf_count_flops(8.0 * n * n * n * nb, algo == 2 ? 6.0 * n * np * np * nb - inverse_blocked_vector_flops() : 0.0);
     }
     c->G = in_b ? c->d_T1 : c->d_A;
     c->W1 = in_b ? c->d_A : c->d_T1;
@@ -406,6 +425,8 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
         // the g(E) cache (ChainGEntry): a launch whose lead and energies were evaluated before only forms Sigma = t g t^H
         ChainGEntry* ent = nullptr;
         bool hit = false;
+        struct Pin { negf_ctx* c; ~Pin() { c->gcache_pinned = false; } } pin{c};      // `ent` points into the cache until this block ends
+        c->gcache_pinned = true;
         if (lds_path && c->gcache_max > 0) {
             std::vector<cplx> tmp;
             ent = gcache_lookup(c, p, host_energies(c, E, nb, tmp), nb, &hit);
@@ -468,6 +489,7 @@ int run_sigma_blocks(negf_ctx* c, SigmaProvider* p, int nb, const cplx* E, int* 
             if (ent) {
                 NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_it, iters, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
                 NEGF_HIP_CHECK(hipMemcpyAsync(ent->d_cv, conv, (size_t)jobs * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                NEGF_HIP_CHECK(hipGetLastError());                 // an entry whose launch failed never becomes a hit
                 ent->valid = true;
             }
             if (can_order && (m0 == 0 || m0 == p->cur_n)) {
@@ -734,6 +756,7 @@ int negf_create(negf_ctx** out, int device)
     c->device = device;
     if (const char* e = getenv("NEGF_CHAIN_CACHE")) c->gcache_max = std::min(std::max(atoi(e), 0), 4096);   // default of negf_set_chain_cache
     c->gcache.reserve((size_t)c->gcache_max);
+    live_contexts().push_back(c);
     *out = c;
     return NEGF_OK;
 }
@@ -741,6 +764,7 @@ int negf_create(negf_ctx** out, int device)
 void negf_destroy(negf_ctx* c)
 {
     if (!c) return;
+    { auto& v = live_contexts(); v.erase(std::remove(v.begin(), v.end(), c), v.end()); }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto* p : c->providers) free_provider(p);

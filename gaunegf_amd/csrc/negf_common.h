@@ -211,6 +211,7 @@ struct negf_ctx {
     cplx* d_acc = nullptr;         // [n*n] result staging
     double* d_scal = nullptr;      // [m_cap][8] scalar outputs
     double* d_site = nullptr;      // [batch][n] per-site DOS staging
+    bool gcache_pinned = false;    // a launch holds a pointer to one of the entries: allocation failures elsewhere must not drop the cache
     int inverse_algo = 0;
     int gamma_algo = 0;            // 0: compact Gamma products when the provider allows, 1: always dense
     cplx* d_gsmall = nullptr;      // small Gamma matrices of a batch (compact path)
@@ -266,6 +267,9 @@ bool launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info)
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info,
                             GjSideStreams* side = nullptr, int win_mode = 0);
 bool inverse_blocked_supported(int n);
+// of the last launch_inverse_blocked: the part of its 6 n np^2 three-real-product flops that ran on the VECTOR pipe
+// (the register-strip window kernels), i.e. was not issued to the matrix cores
+double inverse_blocked_vector_flops();
 
 // acc += sum_b w[b] * X[b]   (fixed summation order, deterministic); `part` is scratch of
 // accumulate_scratch_elems(n2, nb) elements (<= nb * n2 / 32)

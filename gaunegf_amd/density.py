@@ -14,6 +14,7 @@ vectors captured from the reference's own functions (tests/golden/).
     contour_grid            densityComplexN :697-722      GrInt           +Im(.)/pi
     broadening_grid         densityComplexN :730-742      GrInt           (added to the contour)
 """
+import os
 import numpy as np
 from scipy.special import roots_legendre as _scipy_roots_legendre
 import functools
@@ -32,6 +33,7 @@ def roots_legendre(N):
     return _legendre_nodes(int(N))
 
 from .config import (TEMPERATURE, ADAPTIVE_INTEGRATION_TOL, N_KT, MAX_CYCLES, MAX_GRID_POINTS)
+from . import integrate as _integrate
 from .integrate import GrInt, GrLessInt, GrIntSegments, GrLessIntSegments
 
 _ENGINE_GRLESSINT = GrLessInt
@@ -72,9 +74,14 @@ SPECULATIVE_POINTS_SMALL = 512   # ... and for n <= 96 (matrix in registers, sev
                                  # 93 us, 324 points 132 us): every level of the rule, 486 points, in one go
 
 
-def _speculation_budget(F):
-    """How many new nodes an adaptive integration may evaluate ahead of its convergence test, for this system."""
+def _speculation_budget(F, S=None, g=None):
+    """How many new nodes an adaptive integration may evaluate ahead of its convergence test, for this system: zero
+    (level by level, the reference's own sequence) unless the levels really are fused into one pass of the engine
+    (integrate.can_fuse_segments: a device-lowerable ``g``, no energy sharding, no spin-block split) -- otherwise every
+    speculated level would cost a launch of its own, up to 486 nodes where the reference stops after 18."""
     if SPECULATIVE_POINTS <= 0:
+        return 0
+    if g is not None and not _integrate.can_fuse_segments(F, S, g):
         return 0
     n = np.shape(F)[0]
     return SPECULATIVE_POINTS_SMALL if n <= 96 else SPECULATIVE_POINTS_ONE_CU if n <= 256 else SPECULATIVE_POINTS
@@ -323,11 +330,12 @@ def densityReal(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATURE, 
     N = 1
     maxDP = 1e9
     ahead = {}
+    budget = _speculation_budget(F, S, g)
     while N < maxN:
         P_ = P.copy()
         if N not in ahead:
             group, pts, M = [], 0, N
-            while M < maxN and (not group or pts + M <= _speculation_budget(F)):
+            while M < maxN and (not group or pts + M <= budget):
                 group.append(M); pts += M; M *= 2
             if len(group) == 1 or debug or GrInt is not _ENGINE_GRINT:
                 group = [N]
@@ -389,7 +397,7 @@ def densityGrid(F, S, g, mu1, mu2, ind=None, tol=ADAPTIVE_INTEGRATION_TOL, T=TEM
 
     den = integratePointsAdaptiveANT(computePoint, tol=tol, debug=debug,
                                      computeLevels=computeLevels if GrLessInt is _ENGINE_GRLESSINT else None,
-                                     budget=_speculation_budget(F))
+                                     budget=_speculation_budget(F, S, g))
     if debug:
         print('Integration done!')
     return den / (2 * np.pi)
@@ -438,14 +446,14 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
         return integratePointsAdaptiveANT(lambda x, w: GrInt(F, S, g, *grid(x, w)), tol=tol, debug=debug,
                                           computeLevels=(lambda nodes: GrIntSegments(F, S, g, [grid(x, w) for x, w in nodes]))
                                           if GrInt is _ENGINE_GRINT else None,
-                                          budget=_speculation_budget(F))
+                                          budget=_speculation_budget(F, S, g))
 
-    if T > 0 and GrInt is _ENGINE_GRINT and not debug and _speculation_budget(F) > 0:
+    if T > 0 and GrInt is _ENGINE_GRINT and not debug and _speculation_budget(F, S, g) > 0:
         # the contour and the Fermi tail refine together: one launch per round for both (integrateJointlyAdaptiveANT)
         print('Complex Contour Integration (with the Fermi broadening):')
         total, tail = integrateJointlyAdaptiveANT([grid_of(on_arc), grid_of(on_tail)],
                                                   lambda segs: GrIntSegments(F, S, g, segs), tol=tol,
-                                                  budget=_speculation_budget(F))
+                                                  budget=_speculation_budget(F, S, g))
         total += tail
         return (1 + 0j) * np.imag(total) / np.pi
     print('Complex Contour Integration:')
@@ -525,17 +533,30 @@ def _orbital_energies(F, S, hermitian=False):
     return np.sort(np.real(vals))
 
 
+CALC_EMIN_ROUTE = None      # None: the environment (NEGF_CALC_EMIN_ROUTE) decides; "reference" | "fast"
+
+
+def _calc_emin_route():
+    r = CALC_EMIN_ROUTE if CALC_EMIN_ROUTE is not None else os.environ.get("NEGF_CALC_EMIN_ROUTE", "fast")
+    if r not in ("fast", "reference"):
+        raise ValueError(f"NEGF_CALC_EMIN_ROUTE / density.CALC_EMIN_ROUTE must be 'fast' or 'reference', not {r!r}")
+    return r
+
+
 def _lowest_orbital_energy(F, S):
     """min Re eig(inv(S) F) (density.py:822).  The reference takes it from the full non-symmetric eigenproblem; for a
     Hermitian F and a Hermitian positive-definite S of 256 orbitals or more the lowest GENERALISED eigenvalue is the
     same number to rounding (relative 1e-13, measured) and costs a tenth (N = 800: 17 ms against 153 ms, 12 % of a
-    density step).  Smaller systems and anything not exactly Hermitian keep the reference's route, bit for bit."""
+    density step).  Smaller systems and anything not exactly Hermitian keep the reference's route, bit for bit.
+    This is a DEVIATION in the last bits of Emin, and with it of every grid derived from Emin:
+    ``NEGF_CALC_EMIN_ROUTE=reference`` (or ``density.CALC_EMIN_ROUTE = "reference"``) keeps the reference's route for
+    every system, bit for bit (tests/test_adaptive_host.py::test_calc_emin_reference_route_is_bit_identical)."""
     F = np.asarray(F); S = np.asarray(S)
-    if F.shape[0] >= 256 and np.array_equal(F, F.conj().T) and np.array_equal(S, S.conj().T):
+    if _calc_emin_route() == "fast" and F.shape[0] >= 256 and np.array_equal(F, F.conj().T) and np.array_equal(S, S.conj().T):
         try:
             from scipy.linalg import eigh
             return float(eigh(F, S, eigvals_only=True, subset_by_index=[0, 0], check_finite=False)[0])
-        except Exception:                                       # (S not positive definite, ...)
+        except (np.linalg.LinAlgError, ValueError):             # S not positive definite, non-finite input: the reference's route
             pass
     return min(_orbital_energies(F, S))
 

@@ -13,7 +13,10 @@ nccl backend).  No other collective exists.
 
 ``comm_ms_reset()`` / ``comm_ms_total()`` time the collectives themselves (device events
 around the RCCL calls on the stream they are issued on, the host clock for CPU backends),
-so that a multi-GPU bench line can say how much of a step is communication.
+so that a multi-GPU bench line can say how much of a step is communication.  Timing is
+OPT-IN: it starts with ``comm_ms_reset()`` and ends with ``comm_ms_stop()``; without it a
+collective records nothing (an SCF run issues 10^4 ... 10^5 of them), and events that
+have completed are folded into the running total so that the list stays short.
 
 Opt-in: call ``enable()`` after ``torch.distributed.init_process_group``; every rank
 must then call GrInt / GrLessInt / calculate_transmission with the same arguments
@@ -22,20 +25,37 @@ must then call GrInt / GrLessInt / calculate_transmission with the same argument
 import numpy as np
 
 _state = {"enabled": False, "group": None, "single_ok": False}
-_comm = {"events": [], "host_ms": 0.0, "calls": 0}
+_comm = {"events": [], "host_ms": 0.0, "calls": 0, "on": False}
 
 
 def comm_ms_reset():
-    _comm["events"].clear(); _comm["host_ms"] = 0.0; _comm["calls"] = 0
+    """Start (or restart) timing the collectives."""
+    _comm["events"].clear(); _comm["host_ms"] = 0.0; _comm["calls"] = 0; _comm["on"] = True
+
+
+def comm_ms_stop():
+    """Stop timing; the totals stay readable."""
+    _fold(wait=True)
+    _comm["on"] = False
+
+
+def _fold(wait=False):
+    """Move completed event pairs into host_ms (all of them with ``wait``)."""
+    pending = []
+    for a, b in _comm["events"]:
+        if wait:
+            b.synchronize()
+        if wait or b.query():
+            _comm["host_ms"] += a.elapsed_time(b)
+        else:
+            pending.append((a, b))
+    _comm["events"][:] = pending
 
 
 def comm_ms_total():
     """(milliseconds spent in collectives since comm_ms_reset, number of collectives)."""
-    ms = _comm["host_ms"]
-    for a, b in _comm["events"]:
-        b.synchronize()
-        ms += a.elapsed_time(b)
-    return ms, _comm["calls"]
+    _fold(wait=True)
+    return _comm["host_ms"], _comm["calls"]
 
 
 class _timed_collective:
@@ -47,6 +67,9 @@ class _timed_collective:
 
     def __enter__(self):
         import time
+        self.on = _comm["on"]
+        if not self.on:
+            return self
         _comm["calls"] += 1
         if self.cuda:
             import torch
@@ -58,10 +81,14 @@ class _timed_collective:
 
     def __exit__(self, *exc):
         import time
+        if not self.on:
+            return False
         if self.cuda:
             import torch
             self.e1.record(torch.cuda.current_stream(self.dev))
             _comm["events"].append((self.e0, self.e1))
+            if len(_comm["events"]) > 64:
+                _fold()
         else:
             _comm["host_ms"] += (time.perf_counter() - self.t0) * 1e3
         return False

@@ -189,6 +189,16 @@ def GrInt(F, S, g, Elist, weights):
     return _dist.sharded_sum(lambda idx: _partial_gr(engine, g, E[idx], w[idx]), E.size)
 
 
+def can_fuse_segments(F, S, g):
+    """True when GrIntSegments / GrLessIntSegments evaluate several integrals of this system in ONE pass of the engine:
+    ``g`` lowers to a device-side provider, the energy grid is not sharded across ranks and the system is not split
+    into spin blocks.  Everything else falls back to one GrInt per segment -- callers that evaluate levels AHEAD of a
+    convergence test (density._speculation_budget) must not speculate then: every speculated level would be a launch
+    (and, sharded, an all-reduce) of its own."""
+    return hasattr(g, "_negf_lower") and not _dist.is_active() and not _split_depth and \
+        _spin_split(np.asarray(F), np.asarray(S), g) is None
+
+
 def GrIntSegments(F, S, g, segments):
     """``[GrInt(F, S, g, E, w) for (E, w) in segments]`` from ONE pass of the engine over all the energies
     (negf_gr_int_seg) when ``g`` lives on the device; a plain loop of GrInt otherwise (foreign providers, spin-block

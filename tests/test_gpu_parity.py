@@ -1315,13 +1315,58 @@ def test_config_C5_shape(engine):
         assert abs(T[k] - tot) < TOL * max(1.0, abs(tot))
 
 
+def _gapped_system(N, seed):
+    """Real symmetric F, S with the generalised spectrum eig(inv(S) F) in [-5, -3] u [3, 5]: a grid in (-1, 1) sits in a
+    gap, G(E) is real up to the broadening."""
+    rng = np.random.default_rng(seed)
+    _, S = random_system(N, seed)
+    S = np.real(S); S = (S + S.T) / 2
+    L = np.linalg.cholesky(S)
+    Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    d = np.concatenate([rng.uniform(-5, -3, N // 2), rng.uniform(3, 5, N - N // 2)])
+    F = L @ (Q * d) @ Q.T @ L.T
+    return (F + F.T) / 2, S
+
+
+@pytest.mark.parametrize("N,algo", [(300, 0), (300, 3), (300, 4), (650, 0), (650, 3)])
+def test_imaginary_part_in_a_spectral_gap_windowed_inverse(engine, N, algo):
+    """The Im-only bar on the WINDOWED inverse in the regime it is about: a system with a gap built into its spectrum,
+    the grid inside the gap at eta = 1e-4, two contact orbitals per side with Gamma = 2e-3 -- the oracle's ||Im|| is
+    4e-5 ||Re|| (asserted: <= 1e-3), and the imaginary part ALONE of GrInt and of G(E) meets 1e-8 through both
+    window-kernel families (negf_set_inverse_algo 3: register strips, vector FMAs; 4: team kernels, 3M matrix-core
+    updates whose rounding error in Im is relative to |Re|) and through the 3M column updates both share."""
+    from gaunegf_amd.integrate import GrBatch, GrInt
+    from gaunegf_amd.surfGTester import surfGTest
+    F, S = _gapped_system(N, 77 + N)
+    inds = [[0, 1], [N - 2, N - 1]]
+    g_dev = surfGTest(F, S, inds, -1e-3j)
+    g_ref = oracle.ConstSigma(F, S, inds, -1e-3j)
+    E = np.linspace(-1.0, 1.0, 6) + 1e-4j
+    w = np.full(6, 2.0 / 6)
+    ref = oracle.GrInt(F, S, g_ref, E, w)
+    assert np.linalg.norm(ref.imag) < 1e-3 * np.linalg.norm(ref.real)          # (the regime: Im three orders below Re)
+    engine.set_inverse_algo(algo)
+    try:
+        got = GrInt(F, S, g_dev, E, w)
+        G = GrBatch(F, S, g_dev, E[:2])
+    finally:
+        engine.set_inverse_algo(0)
+    assert rel_fro(got.imag, ref.imag) < TOL, (N, algo, rel_fro(got.imag, ref.imag))
+    assert rel_fro(got.real, ref.real) < TOL
+    for k in range(2):
+        r = oracle.gr_point(g_ref.sigmaTot(E[k]), E[k], F, S)
+        assert np.linalg.norm(r.imag) < 1e-3 * np.linalg.norm(r.real)
+        assert rel_fro(G[k].imag, r.imag) < TOL, (N, algo, k, rel_fro(G[k].imag, r.imag))
+
+
 @pytest.mark.parametrize("N", [60, 120, 300])
 def test_imaginary_part_of_the_real_axis_integral(engine, N):
     """The dense kernels form complex products from three real ones (3M: Im = S3 - S1 - S2), whose rounding error in the
     imaginary part is relative to |Re|, not to |Im|.  On a real-axis grid at eta = 1e-6 with weakly coupled contacts the
-    density lives in Im G, orders of magnitude below Re G: the imaginary part ALONE of GrInt and of G(E) must still meet
-    the 1e-8 bar against the oracle (N = 60: the fused small-system kernel; 120: the single-workgroup blocked inverse;
-    300: the windowed inverse with its 3M column updates)."""
+    density lives in Im G, below Re G (||Im|| / ||Re|| = 0.006 / 0.003 / 0.055 for N = 60 / 120 / 300): the imaginary part
+    ALONE of GrInt and of G(E) must still meet the 1e-8 bar against the oracle (N = 60: the fused small-system kernel; 120:
+    the single-workgroup blocked inverse; 300: the windowed inverse -- whose regime proper, three orders below Re, is
+    test_imaginary_part_in_a_spectral_gap_windowed_inverse)."""
     from gaunegf_amd.integrate import GrBatch, GrInt
     from gaunegf_amd.surfGTester import surfGTest
     F, S = random_system(N, 31 + N)
@@ -1333,7 +1378,7 @@ def test_imaginary_part_of_the_real_axis_integral(engine, N):
     w = np.full(24, 4.0 / 24)
     ref = oracle.GrInt(F, S, g_ref, E, w)
     got = GrInt(F, S, g_dev, E, w)
-    assert np.linalg.norm(ref.imag) < 1e-1 * np.linalg.norm(ref.real)          # (the regime the test is about: Im << Re)
+    assert np.linalg.norm(ref.imag) < (1e-2 if N < 300 else 1e-1) * np.linalg.norm(ref.real)     # (the regime: Im << Re)
     assert rel_fro(got.imag, ref.imag) < TOL
     G = GrBatch(F, S, g_dev, E[:3])
     for k in range(3):
