@@ -551,6 +551,18 @@ def worker_c3(args):
                                                            no_cpu=args.no_cpu),
                              # BASELINE configs[0]-sized: 60 basis functions (the ethane demo), 100 real-axis points
                              "C1_N60_x_100": extra_const(eng, 60, 6, 100, 1, reps=20, cpu_budget=2.0, no_cpu=args.no_cpu)}
+    if world > 1 and not args.no_extra:
+        # what BASELINE calls multi-GPU: the FIXED C4 / C5 steps through the product's own sharding over these ranks
+        # (strong scaling), beside the weak C3 line -- the driver's command only passes --gpus N
+        strong = {}
+        for cfg, nsteps in (("c4", 5), ("c5", 2)):
+            l = run_api(cfg, nsteps, 1, 1, torch, dist, world, rank, local_rank, rehearsal,
+                        check_local=os.environ.get("NEGF_BENCH_CHECK_LOCAL", "1" if rehearsal else "0") == "1")
+            if rank == 0:
+                strong[cfg + "_strong"] = strong_summary(l)
+        if rank == 0:
+            line.setdefault("extra", {}).update(strong)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -568,9 +580,35 @@ def _bethe_contacts(N):
     return coords, orbMap, orbTyp
 
 
+ONE_GPU_PROFILES = {"c4": "r05_c4.json", "c5": "r05_c5_bench.json"}      # profiles/: the stored one-GPU lines of --config c4 / c5
+
+
+def one_gpu_ms_per_step(config):
+    """ms per step of the committed one-GPU run of --config c4 / c5 (profiles/), None when there is none."""
+    try:
+        with open(os.path.join(ROOT, "profiles", ONE_GPU_PROFILES[config])) as f:
+            return float(json.load(f)["ms_per_step"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def worker_api(args):
     """BASELINE configs C4 / C5 through the drop-in API with the product's own energy sharding (strong scaling)."""
     torch, dist, world, rank, local_rank, rehearsal = _init_ranks()
+    line = run_api(args.config, args.steps, args.warmup, args.emulate_share, torch, dist, world, rank, local_rank, rehearsal)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_api(config, steps, warmup, emulate_share, torch, dist, world, rank, local_rank, rehearsal, check_local=False):
+    """One strong-scaling measurement of C4 / C5 in an initialised process group: the bench line (rank 0; None elsewhere).
+    ``check_local``: rank 0 also evaluates the step WITHOUT sharding and the line carries the largest relative deviation
+    of the sharded result from it (``sharded_vs_local_rel``)."""
+    import types
+    args = types.SimpleNamespace(config=config, steps=steps, warmup=warmup, emulate_share=emulate_share)
     from gaunegf_amd import distributed as D
     from gaunegf_amd import density as DN
     from gaunegf_amd.engine import get_engine
@@ -654,6 +692,19 @@ def worker_api(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert all(np.all(np.isfinite(np.asarray(r if not isinstance(r, tuple) else r[0]))) for r in res)
+    cm_calls = D.comm_ms_total() if world > 1 else (0.0, 0)
+    D.comm_ms_stop()
+    local_dev = None
+    if check_local and world > 1:
+        # the same step on rank 0 alone, not sharded: what the collectives have to reproduce
+        D.disable()
+        if rank == 0:
+            loc = step()
+            first = lambda r: np.asarray(r if not isinstance(r, tuple) else r[0])
+            local_dev = max(float(np.linalg.norm(first(a) - first(b)) / max(np.linalg.norm(first(b)), 1e-300)) for a, b in zip(res, loc))
+        D.enable()
+        fence()
+    line = None
     if rank == 0:
         inv_ms = prof["inverse"][0]; gm_ms = prof["zgemm"][0]
         # flops as the library counted them for rank 0's launches (negf_profile_read_flops): algorithmic, and issued
@@ -684,14 +735,31 @@ def worker_api(args):
             line["config"]["emulated_share"] = (f"rank 0's share of an {args.emulate_share}-way energy-cyclic sharding run on "
                                                 "one GPU (no collective): the per-GPU batch sizes of the multi-GPU configuration")
         if world > 1:
-            cm, calls = D.comm_ms_total()
+            cm, calls = cm_calls
             line["comm_ms"] = cm / args.steps          # the all-reduces / all-gathers of one step (events around the collectives)
             line["collectives_per_step"] = calls / args.steps
-        print(json.dumps(line), flush=True)
+            one = one_gpu_ms_per_step(args.config)
+            line["one_gpu_ms_per_step"] = one          # profiles/: the committed one-GPU run of the same step
+            line["speedup_vs_one_gpu"] = one / line["ms_per_step"] if one else None
+            if local_dev is not None:
+                line["sharded_vs_local_rel"] = local_dev
     if world > 1:
         dist.barrier()
         D.disable()
-        dist.destroy_process_group()
+    return line
+
+
+def strong_summary(line):
+    """What the headline's ``extra.c4_strong`` / ``extra.c5_strong`` keep of a run_api line."""
+    rl = line["roofline"]
+    return {"workload": line["config"]["workload"], "scaling": "strong", "n_gpus": line["n_gpus"], "steps": line["steps"],
+            "ms_per_step": line["ms_per_step"], "value": line["value"], "unit": line["unit"],
+            "comm_ms": line.get("comm_ms"), "collectives_per_step": line.get("collectives_per_step"),
+            "one_gpu_ms_per_step": line.get("one_gpu_ms_per_step"), "speedup_vs_one_gpu": line.get("speedup_vs_one_gpu"),
+            "sharded_vs_local_rel": line.get("sharded_vs_local_rel"),
+            "inverse": rl["inverse"], "zgemm": rl["zgemm"], "family_ms_per_step": rl["family_ms_per_step"]}
+
+
 
 
 # ------------------------------------------------------------------------- the SCF call pattern

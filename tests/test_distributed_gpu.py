@@ -111,3 +111,31 @@ def test_rccl_legs_on_one_gpu(engine):
     group of ONE rank on the one GPU of the box (RCCL refuses two ranks on one device): the same code path a rank of
     an 8-GPU job runs, collectives included, must reproduce the local integrals."""
     _spawn_and_compare(1, "nccl")
+
+
+def test_bench_gpus_2_rehearsal_carries_the_strong_scaling_blocks():
+    """``bench.py --gpus N`` (the driver's multi-GPU command) keeps the weak C3 line and adds ``extra.c4_strong`` /
+    ``extra.c5_strong``: BASELINE's multi-GPU configurations as FIXED steps through the product's own sharding
+    (distributed.enable, one all-reduce / all-gather per entry point).  Rehearsed here with two ranks on the one GPU over
+    gloo (NEGF_BENCH_REHEARSAL=1): both blocks are present with their timing, communication and roofline fields, and the
+    sharded results equal rank 0's un-sharded evaluation of the same step to 1e-13."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEGF_BENCH_REHEARSAL="1", NEGF_BENCH_CHECK_LOCAL="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--energies", "24", "--no-cpu", "--no-warm"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "comm_ms" in line
+    for key, pts in (("c4_strong", 742), ("c5_strong", 1024)):
+        b = line["extra"][key]
+        assert b["scaling"] == "strong" and b["n_gpus"] == 2 and b["ms_per_step"] > 0
+        assert abs(b["value"] * b["ms_per_step"] * 1e-3 - pts) < 1e-6 * pts          # the FIXED grid, whatever N
+        assert b["comm_ms"] is not None and b["collectives_per_step"] >= 2
+        assert b["sharded_vs_local_rel"] is not None and b["sharded_vs_local_rel"] <= 1e-13, b["sharded_vs_local_rel"]
+        assert 0 < b["inverse"]["frac"] <= 1 and "family_ms_per_step" in b
