@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnegf_hip.so")
+# (NEGF_LIB_PATH: another build of the same library -- A/B runs of kernel variants built with NEGF_EXTRA_HIPCC_FLAGS)
+LIB_PATH = os.environ.get("NEGF_LIB_PATH") or os.path.join(_HERE, "lib", "libnegf_hip.so")
 
 NEGF_OK = 0
 NEGF_EINVAL = -1

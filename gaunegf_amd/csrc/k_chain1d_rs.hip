@@ -64,6 +64,19 @@ constexpr int RS_NB = RS_PANEL;           // panel width of the small inverse: h
 #ifndef RS_RR
 #define RS_RR 1
 #endif
+#ifndef RS_PHAT
+#define RS_PHAT 1                     // 1: the factoring wave stores P - E (E: a one at every (pivot row, its column) of the panel), so that the
+#endif                                //    updates are PURE accumulations W += (P - E) Q -- the pivot rows' old content cancels in the
+                                      //    product instead of being masked per tile (8 compares + 16 selects of the 42 vector
+                                      //    instructions a rank-8 tile update carried beside its 6 matrix instructions); the ones ride
+                                      //    along as constants (every later update is additive, and neither a Q row nor a P operand of a
+                                      //    later panel contains such an element) and are added back where the inverse is read (gather_mix)
+#ifndef RS_UPD_3M
+#define RS_UPD_3M 1                   // trailing / look-ahead updates (K = 8): 1 = three real products per tile and k-step (3M: operand
+#endif                                //    sums and a 12-instruction recombination per tile), 0 = four (no vector work per tile at all)
+#ifndef RS_ABLATE
+#define RS_ABLATE 0                   // diagnostic builds only (wrong results; timing with force_iters): 1 = no panel factoring (the chain
+#endif                                //    wave's pivot steps), 2 = no trailing / look-ahead updates, 4 = no products, 8 = no mixing phase
 #ifndef RS_STAMPS
 #define RS_STAMPS 0                   // 1: diagnostic build -- the phase / cycle stamps of NEGF_CHAIN_STAMPS=1 are compiled in
 #endif                                //    (NEGF_EXTRA_HIPCC_FLAGS=-DRS_STAMPS=1 python -m gaunegf_amd.build --force); the production
@@ -255,6 +268,7 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
     cplx a[RS_NB];                                      //  hoisted out of the fixed-point loop and kept alive)
     bool avail = r < n && colof[r] < 0;
     cplx myip = cmake(1.0, 0.0);
+    int mycol = -1;                                     // the panel column this lane's row is the pivot row of
     cplx* wrow = W + r * P + p0;                        // rows >= n are zero padding
 #pragma unroll
     for (int s = 0; s < RS_NB; ++s) {
@@ -336,13 +350,18 @@ __device__ __forceinline__ void rs_factor(int n, cplx* W, int* pivrow, int* colo
             }
             a[j] = is_piv ? cmake(1.0, 0.0) : coef;
             myip = cmake(is_piv ? ip.x : myip.x, is_piv ? ip.y : myip.y);
+            mycol = is_piv ? j : mycol;
             avail = avail && !is_piv;
         }
     }
     if (r < n) {
 #pragma unroll
         for (int s = 0; s < RS_NB; ++s)
-            if (s < pw) wrow[s] = cmul(a[s], myip);       // the deferred pivot-row scaling
+            if (s < pw) {
+                cplx v = cmul(a[s], myip);                  // the deferred pivot-row scaling
+                if (RS_PHAT && s == mycol) v.x -= 1.0;      // P - E (see RS_PHAT)
+                wrow[s] = v;
+            }
     }
 }
 
@@ -383,14 +402,14 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
         cplx cv[4], pa[NKS];
         int cf[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { cf[r] = colof[ti * 16 + fk + 4 * r]; cv[r] = cbase[4 * r * P]; }
+        for (int r = 0; r < 4; ++r) { if (!RS_PHAT) cf[r] = colof[ti * 16 + fk + 4 * r]; cv[r] = cbase[4 * r * P]; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) pa[ks] = pbase[ks * 4];
-        constexpr bool M3 = P > 35;                         // 3M (mfma3) in the 168-VGPR kernels
+        constexpr bool M3 = RS_UPD_3M && P > 35;            // 3M (mfma3) in the 168-VGPR kernels
         d4 ua, ub = {0, 0, 0, 0}, uc;                       // accumulators, seeded with the old tile
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool keep = !(cf[r] >= p0 && cf[r] < p0 + pw);
+            const bool keep = RS_PHAT || !(cf[r] >= p0 && cf[r] < p0 + pw);
             ua[r] = keep ? cv[r].x : 0.0; uc[r] = keep ? (M3 ? cv[r].x + cv[r].y : cv[r].y) : 0.0;
         }
 #pragma unroll
@@ -411,12 +430,12 @@ __device__ __forceinline__ void rs_update_tile(int n, cplx* W, const int* colof,
         const bool mine = !(rowstrip && colstrip) || (fi >> 2) == 0;      // the corner block exists four times
         const cplx* prow = W + (rowstrip ? TR * 16 + (fi & 3) : ti * 16 + fi) * P + p0 + fk;
         cplx* cptr = W + row * P + col;
-        const int cf = colof[row];
+        const int cf = RS_PHAT ? -1 : colof[row];
         const cplx cv = *cptr;
         cplx pa[NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) pa[ks] = prow[ks * 4];
-        const bool keep = !(cf >= p0 && cf < p0 + pw);
+        const bool keep = RS_PHAT || !(cf >= p0 && cf < p0 + pw);
         double ua = keep ? cv.x : 0.0, ub = 0.0, uc = keep ? cv.x + cv.y : 0.0;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
@@ -446,7 +465,7 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
     }
     const int col = tj * 16 + fi;
     const bool colin = col >= clo && col < chi;             // this lane's column is one of those to be updated
-    constexpr bool M3 = P > 35;                              // 3M (mfma3) in the 168-VGPR kernels
+    constexpr bool M3 = RS_UPD_3M && P > 35;                 // 3M (mfma3) in the 168-VGPR kernels
     double qs[NKS];                                          // 3M: re + im of the Q fragment, once per column tile
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qs[ks] = qf[ks].x + qf[ks].y;
@@ -459,7 +478,7 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
     int cf[2][4];
     auto fetch = [&](int ti, int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { cf[s][r] = cfb[ti * 16 + 4 * r]; cv[s][r] = cbase[(ti * 16 + 4 * r) * P]; }
+        for (int r = 0; r < 4; ++r) { if (!RS_PHAT) cf[s][r] = cfb[ti * 16 + 4 * r]; cv[s][r] = cbase[(ti * 16 + 4 * r) * P]; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) pa[s][ks] = pbase[ti * 16 * P + ks * 4];   // k >= pw pairs with qf == 0 (finite element)
     };
@@ -471,7 +490,7 @@ __device__ __forceinline__ void rs_update_col(int n, cplx* W, const int* pivrow,
         d4 ua, ub = {0, 0, 0, 0}, uc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool keep = !(cf[s][r] >= p0 && cf[s][r] < p0 + pw);
+            const bool keep = RS_PHAT || !(cf[s][r] >= p0 && cf[s][r] < p0 + pw);
             ua[r] = keep ? cv[s][r].x : 0.0; uc[r] = keep ? (M3 ? cv[s][r].x + cv[s][r].y : cv[s][r].y) : 0.0;
         }
 #pragma unroll
@@ -533,7 +552,7 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
             if (wave == fw) rs_wait_count(&la_cnt[1], la_epoch);
 #else
             __syncthreads();
-            if (wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, tl, p0, pw, fi, fk, qf, n0, n0 + RS_NB);
+            if (!(RS_ABLATE & 2) && wave < T16 && wave * 16 < n) rs_update_tile<P, RS_NB / 4, TR>(n, W, colof, wave, tl, p0, pw, fi, fk, qf, n0, n0 + RS_NB);
             __syncthreads();
 #endif
         }
@@ -559,7 +578,7 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
                 if (clo >= chi || clo >= n) continue;
                 const bool mine = (!has_next || wave != fw) && (cnt % team == me);
                 ++cnt;
-                if (mine) {
+                if (mine && !(RS_ABLATE & 2)) {
                     // a narrow last panel (<= 4 columns) runs one k-step
                     if (pw <= 4) rs_update_col<T16, P, 1, TR>(n, W, pivrow, colof, tj, p0, pw, lane, clo, chi);
                     else rs_update_col<T16, P, RS_NB / 4, TR>(n, W, pivrow, colof, tj, p0, pw, lane, clo, chi);
@@ -571,7 +590,8 @@ __device__ __forceinline__ void rs_inverse(int n, cplx* W, int* pivrow, int* col
             // the factoring wave is its workgroup's critical path (the others wait for it at the barrier):
             // it goes first when it shares its SIMD's issue slots with waves of the other workgroups
             if (RS_PRIO) __builtin_amdgcn_s_setprio(3);
-            rs_factor<P>(n, W, pivrow, colof, rowline, n0, nw, lane, (st && sgi + 1 == 1) ? st + 40 : nullptr);
+            if (!(RS_ABLATE & 1)) rs_factor<P>(n, W, pivrow, colof, rowline, n0, nw, lane, (st && sgi + 1 == 1) ? st + 40 : nullptr);
+            else if (lane < nw) { pivrow[n0 + lane] = n0 + lane; colof[n0 + lane] = n0 + lane; }
             if (RS_PRIO) __builtin_amdgcn_s_setprio(0);
             if (st && lane == 0) st[17 + 2 * (sgi + 1)] = __builtin_amdgcn_s_memrealtime();
         }
@@ -829,7 +849,8 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         int pr[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) pr[ks] = ks < ksteps ? pvr[ks * 4] : 0;
-        const cplx* gsrc = Ws + colof[colc];
+        const int cfc = colof[colc];
+        const cplx* gsrc = Ws + cfc;
         cplx go[KS], gm[KS];
         if (!first) {
 #pragma unroll
@@ -838,6 +859,12 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) gm[ks] = ks < ksteps ? gsrc[pr[ks] * P] : cmake(0.0, 0.0);
+        if (RS_PHAT) {
+            // the work matrix holds  (reduced M) - E : element (pivrow[c], c) is one short for every column c.  g_new[k][col]
+            // = W[pivrow[k]][colof[col]] is such an element exactly when colof[col] == k
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) gm[ks].x += (cfc == ks * 4 + fk) ? 1.0 : 0.0;
+        }
         if (st && tid == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st[5] = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[6] = __builtin_amdgcn_s_memrealtime(); }
         bool lane_over = false, lane_ok = true;
         if (!first) {
@@ -954,7 +981,8 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
         if (!gc_hit && !skip) {
             rs_inverse<T16, P, REM ? TR : -1>(n, Ws, pivrow, colof, rowline, tid, wave, chain_roles, la_cnt, la_epoch, st ? st + 8 : nullptr);   // st + 8: stage stamps, st + 24: factor
             if (st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
-            gather_mix(first, st);
+            if (!(RS_ABLATE & 8) || first) gather_mix(first, st);
+            else { if (tid < 64) colof[tid] = -1; __syncthreads(); }
             if (st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
             if (!first) ++count;
             first = false;
@@ -988,14 +1016,18 @@ __global__ __launch_bounds__(RS_THREADS, OCC) void chain1d_rs_kernel(
             q_end = count + a.rr_quantum;
         }
         d4 mr[T16], mi[T16], mc[T16];
+        if (RS_ABLATE & 4) {
+#pragma unroll
+            for (int t = 0; t < T16; ++t) { mr[t] = (d4){1e-3, 0, 0, 0}; mi[t] = mr[t]; mc[t] = mr[t]; }
+        }
         // T = B g : row tile `wave`; g is read from Ws by every wave, so T waits in registers
-        gemm_rowtile(mr, mi, mc);
+        if (!(RS_ABLATE & 4)) gemm_rowtile(mr, mi, mc);
         __syncthreads();
         store_rowtile(mr, mi, mc);
         __syncthreads();
         if (st && tid == 0) st[3] = __builtin_amdgcn_s_memrealtime();
         // T B^H : column tile `wave`
-        gemm_coltile(mr, mi, mc);
+        if (!(RS_ABLATE & 4)) gemm_coltile(mr, mi, mc);
         const int fis = rs_opaque(lane & 15), fks = rs_opaque(lane >> 4);
         if (final_pass) {
             cplx* out = blk + (size_t)b * a.blk_stride + off;

@@ -674,7 +674,7 @@ def calcFermi(g, ne, Emin, Emax, fermiGuess=0, N1=100, N2=50, Eminf=ENERGY_MIN, 
     Ncurr = -1
     counter = 0
     lBound, uBound = Emin, Emax
-    print('Calculating Fermi energy using bisection:')
+    print('[getFermiContact] bisecting for the contact Fermi level')
     while abs(ne - Ncurr) > tol and uBound - lBound > tol / 10 and counter < maxcycles:
         g.setF(g.F, fermi, fermi)
         p_ = np.real(low(0) + upper(fermi))
@@ -689,8 +689,8 @@ def calcFermi(g, ne, Emin, Emax, fermiGuess=0, N1=100, N2=50, Eminf=ENERGY_MIN, 
         print("DN:", dN, "Fermi:", fermi, "Bounds:", lBound, uBound)
         counter += 1
     if abs(ne - Ncurr) > tol and counter > maxcycles:
-        print(f'Warning: Fermi energy still not within tolerance! Ef = {fermi:.2f} eV, N = {Ncurr:.2f})')
-    print(f'Finished after {counter} iterations, Ef = {fermi:.2f}')
+        print(f'[getFermiContact] tolerance not reached: Ef = {fermi:.2f} eV with N = {Ncurr:.2f}')
+    print(f'[getFermiContact] {counter} bisection steps, Ef = {fermi:.2f} eV')
     return fermi, Emin, N1, N2
 
 
@@ -735,7 +735,7 @@ def calcFermiBisect(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI
     (The reference passes (S, F) swapped to its DOS kernel at :1176; the intended (F, S) is used.)"""
     assert ne < len(g.F), "Number of electrons cannot exceed number of basis functions!"
     pMu = _mu_density(g, Emin, N, tol, T)
-    E = Ef + 0.0
+    E = Ef
     dE = tol
     counter = 0
     g.setF(g.F, E, E)
@@ -743,11 +743,11 @@ def calcFermiBisect(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI
     Ncurr = np.trace(P @ g.S).real
     while None in [uBound, lBound] and counter < maxcycles:
         if Ncurr > ne:
-            uBound = E + 0.0
+            uBound = E
             Ef = uBound
             E -= dE
         if Ncurr < ne:
-            lBound = E + 0.0
+            lBound = E
             Ef = lBound
             E += dE
         dos = _compute_dos_at_energy(E, g.F, g.S, g.sigmaTot(E))
@@ -759,9 +759,9 @@ def calcFermiBisect(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI
     while abs(ne - Ncurr) > conv and counter < maxcycles and uBound != lBound:
         dN = ne - Ncurr
         if dN > 0 and Ef > lBound:
-            lBound = Ef + 0.0
+            lBound = Ef
         elif dN < 0 and Ef < uBound:
-            uBound = Ef + 0.0
+            uBound = Ef
         Ef = (uBound + lBound) / 2
         dE = uBound - lBound
         counter += 1
@@ -770,9 +770,9 @@ def calcFermiBisect(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI
             P = pMu(Ef)
             Ncurr = np.trace(P @ g.S)
     if counter == maxcycles:
-        print(f'Warning: Max cycles reached, convergence = {abs(Ncurr-ne):.2E}')
+        print(f'[calcFermiBisect] stopped at the cycle limit; |N - ne| = {abs(Ncurr-ne):.2E}')
     elif uBound == lBound:
-        print(f'Warning: Bisection failed, convergence = {abs(Ncurr-ne):.2E}')
+        print(f'[calcFermiBisect] the bracket closed without reaching the tolerance; |N - ne| = {abs(Ncurr-ne):.2E}')
     return Ef, dE, P
 
 
@@ -792,16 +792,16 @@ def calcFermiSecant(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI
         P = pMu(Ef)
         nNext = np.trace(P @ g.S).real
         if abs(nNext - nCurr) < 1e-10:
-            print('Warning: change in ne low, reducing step size')
+            print('[calcFermiSecant] the electron count did not respond to the step: trying a tenth of it')
             dE *= 0.1
             counter += 1
             continue
         dE = dE * ((ne - nCurr) / (nNext - nCurr)) - dE
-        nCurr = nNext + 0.0
+        nCurr = nNext
         counter += 1
     Ef += dE
     if counter == maxcycles:
-        print(f'Warning: Max cycles reached, convergence = {abs(nCurr-ne):.2E}')
+        print(f'[calcFermiSecant] stopped at the cycle limit; |N - ne| = {abs(nCurr-ne):.2E}')
     return Ef, dE, P, abs(nCurr - ne)
 
 
@@ -860,7 +860,7 @@ def calcFermiMuller(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERMI
             break
         counter += 1
     if counter == maxcycles:
-        print(f'Warning: Max cycles reached, convergence = {abs(n2):.2E}')
+        print(f'[calcFermiMuller] stopped at the cycle limit; |N - ne| = {abs(n2):.2E}')
     return E2, dE, P, abs(n2), uBound, lBound
 
 
@@ -924,5 +924,5 @@ def calcFermiPolyFit(g, ne, Emin, Ef, N, tol=ADAPTIVE_INTEGRATION_TOL, conv=FERM
             break
         counter += 1
     if counter >= maxcycles:
-        print(f'Warning: Max cycles reached, convergence = {abs(n):.2E}')
+        print(f'[calcFermiPolyFit] stopped at the cycle limit; |N - ne| = {abs(n):.2E}')
     return E, dE, P, abs(n), uBound, lBound

@@ -30,6 +30,12 @@ PY
     ablate) for d in 0 1 2 3 4 8 12 15; do echo "NEGF_GJ_STRIP_DBG=$d"; NEGF_GJ_SPLIT_MAX=0 NEGF_GJ_PAIR=0 NEGF_GJ_STRIP_DBG=$d KS_N=${KS_N:-500} bash scripts/gpu_r5.sh kstats 2>&1 | grep "strip_kernel"; done ;;
     stamps) NEGF_GJ_STAMPS=1 timeout -k 10 300 python scripts/time_midsize.py ${KS_N:-500} 2>&1 | grep -E "stamps|^n=" | tail -3 | tee gpurun_out/r5_stamps.log ;;
     cfg_ab) for v in 0 1; do echo "NEGF_GJ_STRIP_CFG=$v"; NEGF_GJ_STRIP_CFG=$v KS_N="300 500" bash scripts/gpu_r5.sh stamps; NEGF_GJ_STRIP_CFG=$v timeout -k 10 300 python scripts/time_midsize.py 300 400 500 2>&1 | grep "^n="; done 2>&1 | tee gpurun_out/r5_cfg_ab.log ;;
+    chain_ab) # A/B of chain-kernel builds: the tree's library and the variants under gaunegf_amd/lib/libnegf_hip_<name>.so (CHAIN_LIBS)
+       for L in ${CHAIN_LIBS:-default}; do
+         if [ "$L" = default ]; then unset NEGF_LIB_PATH; else export NEGF_LIB_PATH=$GRAFT_REPO_ROOT/gaunegf_amd/lib/libnegf_hip_$L.so; fi
+         echo "--- lib $L"; timeout -k 10 300 python scripts/time_chain_uniform.py 2>&1 | grep "energies" | head -2; timeout -k 10 300 python scripts/time_chain.py 2>&1 | tail -3
+       done 2>&1 | tee gpurun_out/r5_chain_ab.log; unset NEGF_LIB_PATH ;;
+    chain_tests) timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "chain or C3 or surfG or sigma" > gpurun_out/r5_chain_tests.log 2>&1; rc=$?; tail -3 gpurun_out/r5_chain_tests.log; [ $rc -eq 0 ] || exit $rc ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
