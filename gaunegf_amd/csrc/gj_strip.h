@@ -34,6 +34,25 @@
 // lesson of the chain kernel).
 #pragma once
 
+// maximum of a 32-bit key over the wave (all lanes active), wave-uniform: four DPP steps inside the rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 carry the row maxima into lane 63 (the chain kernel's rs_wave_max_u32)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned strip_dpp_max_u32(unsigned k)
+{
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, CTRL, ROW_MASK, 0xF, true);
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned strip_wave_max_u32(unsigned k)
+{
+    k = strip_dpp_max_u32<0xB1>(k);            // quad_perm [1,0,3,2]
+    k = strip_dpp_max_u32<0x4E>(k);            // quad_perm [2,3,0,1]
+    k = strip_dpp_max_u32<0x141>(k);           // row_half_mirror
+    k = strip_dpp_max_u32<0x140>(k);           // row_mirror: every lane of a row holds the row maximum
+    k = strip_dpp_max_u32<0x142, 0xA>(k);      // row_bcast:15 into rows 1 and 3
+    k = strip_dpp_max_u32<0x143, 0xC>(k);      // row_bcast:31 into rows 2 and 3: lane 63 holds the maximum
+    return (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+}
+
 template <int RPL, int SW, int NW, int OCC, int PF /* chunks of 4 columns in flight in the forward / backward loops */>
 __global__ __launch_bounds__(NW * 64, OCC) void gj_window_strip_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB /* unused */, size_t mat_stride, int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw,
@@ -194,35 +213,58 @@ __global__ __launch_bounds__(NW * 64, OCC) void gj_window_strip_kernel(
             }
         }
         stamp(2);
-        // ---- 3. factor the strip: SW pivot steps, one barrier each
-        auto publish = [&](int J, const cplx (&col)[RPL]) __attribute__((always_inline)) {
-            u64 key = 0;
+        // ---- 3. factor the strip: SW pivot steps, one barrier each.  The step is a latency chain (2.4 us per column in the
+        // first version, at 12 matrices on an idle chip), so it is written for its dependent path:
+        //   * a pivot row is NOT scaled at its step (multiplier 0, a one in the pivot column; myip remembers 1 / pivot) but
+        //     once at the end of the sub-window -- the later steps act linearly on it -- so every wave runs the same
+        //     select-free update and no wave is the slow one at the barrier (the chain kernel's rs_factor idiom);
+        //   * the next column is updated FIRST and its candidate search started on it (|re| + |im| compared on the high
+        //     word of the double, one v_max_u32 per DPP step, lowest lane among equals: ties within 2^-20 go to the lane, across
+        //     waves to the lower row), so that the reduction's latency overlaps the update of the other columns;
+        //   * 1 / |pivot|^2 by v_rcp_f64 and two Newton steps.
+        cplx myip[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) myip[q] = cmake(1.0, 0.0);
+        // candidate of this wave for column J: (high word of the largest |.|_1 among its available rows) -> key, row -> LDS
+        auto search = [&](const cplx (&col)[RPL], unsigned& hi, int& qb) __attribute__((always_inline)) {
+            hi = 0u; qb = 0;
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 const double v = cabs1(col[q]);
-                const u64 k = (avail[q] & (v == v)) ? cand_key(v, row[q]) : 0ull;
-                key = k > key ? k : key;
+                const unsigned h = (avail[q] && v == v) ? (unsigned)__double2hiint(v) : 0u;
+                if (h > hi) { hi = h; qb = q; }
             }
-            key = wave_max_u64(key);
-            const int brow = 0xFFFF - (int)(key & 0xFFFFull);            // meaningless when key == 0
+        };
+        auto publish = [&](int J, unsigned hi, int qb) __attribute__((always_inline)) {
+            const unsigned m = strip_wave_max_u32(hi);
+            const unsigned long long bal = __ballot(hi == m);
+            const int wl = (int)__ffsll((unsigned long long)bal) - 1;     // lowest lane that holds the maximum
             cplx* cn = &cand[J & 1][wave][0];
+            u64 key = 0;
+            if (m != 0) {
+                const int brow = __builtin_amdgcn_readlane(qb, wl) * T + wave * 64 + wl;
+                key = ((u64)m << 16) | (u64)(0xFFFF - brow);
 #pragma unroll
-            for (int q = 0; q < RPL; ++q)
-                if (key != 0 && row[q] == brow) {
+                for (int q = 0; q < RPL; ++q)
+                    if (lane == wl && qb == q) {
 #pragma unroll
-                    for (int j = 0; j < SW; ++j) cn[j] = a[q][j];
-                }
+                        for (int j = 0; j < SW; ++j) cn[j] = a[q][j];
+                    }
+            }
             if (lane == 0) keys[J & 1][wave] = key;
         };
         {
             cplx col[RPL];
 #pragma unroll
             for (int q = 0; q < RPL; ++q) col[q] = a[q][0];
-            publish(0, col);
+            unsigned hi; int qb;
+            search(col, hi, qb);
+            publish(0, hi, qb);
         }
         // (template recursion, not a loop: "#pragma unroll" gives up on 32 steps of this size and the strip lands on the stack)
         auto steps = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
             constexpr int J = decltype(jc)::value;
+            constexpr int JN = J + 1 < SW ? J + 1 : J;                   // the next column (updated first)
             if (J < ws && !(dbg & 4)) {                                   // (uniform)
                 auto sst = [&](int slot) __attribute__((always_inline)) {    // in-step stamps of column 4, sub-window 1
 #if defined(GJ_STRIP_STEP_STAMPS)       // diagnostic build only (NEGF_EXTRA_HIPCC_FLAGS=-DGJ_STRIP_STEP_STAMPS): costs registers
@@ -232,8 +274,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void gj_window_strip_kernel(
                 sst(0);
                 __syncthreads();
                 sst(1);
-                // the winning candidate.  key == 0: no usable row (a column of NaNs) -- the step then runs with no pivot
-                // row and the matrix is reported through info; (key >> 16) == 0: the column maximum is exactly zero
+                // the winning candidate.  key == 0: no usable row (a column of zeros / NaNs) -- the step then runs with no
+                // pivot row and the matrix is reported through info
                 u64 key = 0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) { const u64 k = keys[J & 1][w]; key = k > key ? k : key; }
@@ -241,54 +283,67 @@ __global__ __launch_bounds__(NW * 64, OCC) void gj_window_strip_kernel(
                 const int pphys = none ? -1 : 0xFFFF - (int)(key & 0xFFFFull);
                 const int ww = none ? 0 : (pphys % T) >> 6;
                 if (tid == 0) {
-                    if ((key >> 16) == 0 && bad_sh == 0) bad_sh = cs + J + 1;
+                    if (none && bad_sh == 0) bad_sh = cs + J + 1;
                     piv_lds[K + J] = none ? 0 : pphys;
                 }
                 sst(2);
                 const cplx* prow = &cand[J & 1][ww][0];
                 const cplx pv = prow[J];
-                const double sc = 1.0 / (pv.x * pv.x + pv.y * pv.y);
+                const double d = pv.x * pv.x + pv.y * pv.y;
+                double sc = __builtin_amdgcn_rcp(d);
+                sc = fma(sc, fma(-d, sc, 1.0), sc);
+                sc = fma(sc, fma(-d, sc, 1.0), sc);
                 const cplx ip = cmake(pv.x * sc, -pv.y * sc);
                 sst(3);
-                cplx nfm[RPL];
+                cplx coef[RPL];
                 bool isp[RPL];
 #pragma unroll
-                for (int q = 0; q < RPL; ++q) { nfm[q] = cneg(cmul(a[q][J], ip)); isp[q] = row[q] == pphys; }
-                // every row takes  row - (f / pivot) * pivot row;  the lane that holds the pivot row then overwrites
-                // it with (pivot row) / pivot (a divergent fix-up that only the pivot's wave executes)
+                for (int q = 0; q < RPL; ++q) {
+                    isp[q] = row[q] == pphys;
+                    const cplx mf = cneg(cmul(a[q][J], ip));
+                    coef[q] = cmake(isp[q] ? 0.0 : mf.x, isp[q] ? 0.0 : mf.y);
+                    avail[q] = avail[q] && !isp[q];
+                    pivnow[q] = pivnow[q] || isp[q];
+                    myip[q] = cmake(isp[q] ? ip.x : myip[q].x, isp[q] ? ip.y : myip[q].y);
+                }
+                // the next column first, and its candidate search started
+                unsigned hi = 0u; int qb = 0;
+                if constexpr (J + 1 < SW) {
+                    const cplx rn = prow[JN];
+                    cplx col[RPL];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) { a[q][JN] = cfma(a[q][JN], coef[q], rn); col[q] = a[q][JN]; }
+                    search(col, hi, qb);
+                }
 #pragma unroll
                 for (int j0 = 0; j0 < SW; j0 += 4) {
                     cplx rb[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) rb[j] = prow[j0 + j];
 #pragma unroll
-                    for (int q = 0; q < RPL; ++q) {
+                    for (int q = 0; q < RPL; ++q)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) a[q][j0 + j] = cfma(a[q][j0 + j], nfm[q], rb[j]);
-                        if (isp[q]) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) a[q][j0 + j] = cmul(ip, rb[j]);
-                        }
-                    }
+                        for (int j = 0; j < 4; ++j)
+                            if (j0 + j != J && !(J + 1 < SW && j0 + j == JN)) a[q][j0 + j] = cfma(a[q][j0 + j], coef[q], rb[j]);
                 }
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) a[q][J] = cmake(isp[q] ? 1.0 : coef[q].x, isp[q] ? 0.0 : coef[q].y);
                 sst(4);
-#pragma unroll
-                for (int q = 0; q < RPL; ++q) {
-                    a[q][J] = cmake(isp[q] ? ip.x : nfm[q].x, isp[q] ? ip.y : nfm[q].y);
-                    avail[q] = avail[q] && !isp[q];
-                    pivnow[q] = pivnow[q] || isp[q];
-                }
-                if (J + 1 < SW && J + 1 < ws) {
-                    cplx col[RPL];
-#pragma unroll
-                    for (int q = 0; q < RPL; ++q) col[q] = a[q][J + 1 < SW ? J + 1 : 0];
-                    publish(J + 1, col);
+                if constexpr (J + 1 < SW) {
+                    if (J + 1 < ws) publish(J + 1, hi, qb);
                 }
                 sst(5);
                 if constexpr (J + 1 < SW) self(self, std::integral_constant<int, J + 1>());
             }
         };
         steps(steps, std::integral_constant<int, 0>());
+        // the deferred scaling of the pivot rows
+#pragma unroll
+        for (int q = 0; q < RPL; ++q)
+            if (pivnow[q]) {
+#pragma unroll
+                for (int j = 0; j < SW; ++j) a[q][j] = cmul(a[q][j], myip[q]);
+            }
         stamp(3);
         // ---- 4. the strip back; this sub-window's pivots into the global bookkeeping
 #pragma unroll

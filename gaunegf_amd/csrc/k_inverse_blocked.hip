@@ -1450,16 +1450,17 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     static int winla = -1;
     if (winla < 0) { const char* e = getenv("NEGF_GJ_WINLA"); winla = e ? atoi(e) : 1; }
     // Which window kernel (win_mode 0 = auto, 1 = strip wherever an instantiation serves n, 2 = team kernels only;
-    // NEGF_GJ_STRIP = 0 / 1 sets the auto rule's answer for A/B runs).  Measured on MI355X, inverse ms per 1000 matrices,
-    // strip / team: n = 256 4.01 / 5.26 (single-workgroup kernel), 300 7.06 / 7.53, 400 13.8 / 14.6, 500 22.3 / 24.5 --
-    // the strip kernel moves 3.3 MB per window and matrix instead of 4.9, and both run at the ~4.3 TB/s this access
-    // pattern gets out of the memory system; n = 650 56.7 / 54.1, 800 85.9 / 83.6, 1000 146.5 / 147.2 (the 8-wave, one-per-CU
-    // form: no gain), and small stream groups (a lean 4-wave workgroup has a longer chain per matrix than the 12-wave
-    // look-ahead kernel): 250 x n = 500 in four groups 6.57 / 6.11, 64 x n = 500 3.32 / 2.65.
+    // NEGF_GJ_STRIP = 0 / 1 sets the auto rule's answer for A/B runs).  Measured on MI355X, inverse ms, strip / team:
+    //   1000 matrices: n = 256 4.01 / 5.26 (single-workgroup kernel), 300 6.62 / 7.53, 400 13.0 / 14.6, 500 21.5 / 24.5 (the
+    //   strip kernel moves 3.3 MB per window and matrix instead of 4.9, and both run at the ~4.3 TB/s this access pattern
+    //   gets out of the memory system), 650 55.5 / 53.5, 800 84.8 / 84.4, 1000 147.9 / 150.4 (the 8-wave, one-per-CU form);
+    //   small batches (stream groups of m / 4): 32 x n = 500 2.29 / 2.20, 128 x 500 4.10 / 3.97, 250 x 500 6.20 / 6.12 (a lean
+    //   4-wave workgroup has a longer chain per matrix than the 12-wave look-ahead kernel), 12 x 800 5.51 / 5.77,
+    //   61 x 800 7.54 / 8.10, 64 x 1000 13.1 / 14.1, 128 x 1000 23.0 / 23.9, 486 x 800 42.5 / 42.4.
     static int strip_env = -2;
     if (strip_env == -2) { const char* e = getenv("NEGF_GJ_STRIP"); strip_env = e ? atoi(e) : -1; }
     static int strip_min = -1;           // matrices per stream group from which the auto rule takes the strip kernel (257 <= n <= 512)
-    if (strip_min < 0) { const char* e = getenv("NEGF_GJ_STRIP_MIN"); strip_min = e ? atoi(e) : 192; }
+    if (strip_min < 0) { const char* e = getenv("NEGF_GJ_STRIP_MIN"); strip_min = e ? atoi(e) : 64; }
     static int strip_cfg = -1;           // 0: the measured choice per size; 1: n <= 512 fat (8 waves x 1 row, sub-windows of 32); 3: n <= 256 with sub-windows of 16; 4: n <= 512 lean with two chunks in flight
     if (strip_cfg < 0) { const char* e = getenv("NEGF_GJ_STRIP_CFG"); strip_cfg = e ? atoi(e) : 0; }
     static int strip_dbg = -1;           // timing ablations of the strip kernel (wrong results)
@@ -1480,7 +1481,7 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         auto window = [&](int c0, int cw) {
             unsigned long long* stp = (c0 == WIN && first == 0) ? d_stamps : (unsigned long long*)nullptr;
             // (matrix-core flop accounting: with the strip kernel the window's own 6 n cw^2 are vector work)
-            const bool strip = NBI == 16 && (win_mode == 1 || (win_mode == 0 && (strip_env >= 0 ? strip_env != 0 : (n <= 256 || (n <= 512 && count >= strip_min)))));
+            const bool strip = NBI == 16 && (win_mode == 1 || (win_mode == 0 && (strip_env >= 0 ? strip_env != 0 : (n <= 256 || (n <= 512 ? count >= strip_min : (count <= 160 || n >= 900))))));
             if (strip) {
                 g_gj_vector_flops += 6.0 * (double)((n + 15) & ~15) * cw * (double)cw * count;
                 if (n <= 256 && strip_cfg != 3)
@@ -1592,7 +1593,7 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
         unsigned long long h[64];
         (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
         auto us = [&](int i) { return (double)(h[i] - h[0]) / 100.0; };
-        if (NBI == 16 && (win_mode == 1 || (win_mode == 0 && strip_env != 0 && n <= 512))) {
+        if (NBI == 16 && (win_mode == 1 || (win_mode == 0 && strip_env != 0))) {
             fprintf(stderr, "[gj strip stamps] n=%d window 1, workgroup 0 (us since the window's start):", n);
             for (int sp = 0; sp < 4; ++sp)
                 fprintf(stderr, " | sub %d: top %.1f loaded %.1f forward %.1f factored %.1f stored %.1f staged %.1f backward %.1f", sp,

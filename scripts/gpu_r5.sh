@@ -36,6 +36,15 @@ PY
          echo "--- lib $L"; timeout -k 10 300 python scripts/time_chain_uniform.py 2>&1 | grep "energies" | head -2; timeout -k 10 300 python scripts/time_chain.py 2>&1 | tail -3
        done 2>&1 | tee gpurun_out/r5_chain_ab.log; unset NEGF_LIB_PATH ;;
     chain_tests) timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "chain or C3 or surfG or sigma" > gpurun_out/r5_chain_tests.log 2>&1; rc=$?; tail -3 gpurun_out/r5_chain_tests.log; [ $rc -eq 0 ] || exit $rc ;;
+    small_stamps) for v in 1 0; do echo "NEGF_GJ_STRIP=$v"; NEGF_GJ_STRIP=$v NEGF_GJ_STAMPS=1 timeout -k 10 300 python scripts/time_smallbatch.py ${SMALL_CASES:-800x12} 2>&1 | grep -E "stamps|^n=" | tail -3; done | tee gpurun_out/r5_small_stamps.log ;;
+    small_kstats) rm -rf gpurun_out/r5_skstats; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5_skstats -o ks -- python3 $GRAFT_REPO_ROOT/scripts/time_smallbatch.py ${SMALL_CASES:-800x12} > $GRAFT_REPO_ROOT/gpurun_out/r5_skstats.log 2>&1; rc=$?; cd $GRAFT_REPO_ROOT; [ $rc -eq 0 ] || { tail -20 gpurun_out/r5_skstats.log; exit $rc; }
+       grep "^n=" gpurun_out/r5_skstats.log; f=$(find gpurun_out/r5_skstats -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:10]:
+    print(f"{r['Name'][:100]:100s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} avg_us {float(r['AverageNs'])/1e3:9.1f} {r['Percentage']}%")
+PY
+       find gpurun_out/r5_skstats -name "*.db" -delete; find gpurun_out/r5_skstats -name "*trace.csv" -delete ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
