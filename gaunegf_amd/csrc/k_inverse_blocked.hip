@@ -1223,12 +1223,16 @@ __global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
                 cr[a][r] = z ? 0.0 : cv[a][r].x; ci[a][r] = z ? 0.0 : cv[a][r].x + cv[a][r].y;
             }
         const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
-        cplx af[2][2];
+        // (A fragments two k-steps ahead of their matrix instructions, held there by scheduling barriers: see gj_colupdate2_kernel)
+        constexpr int CU_LA = 2;
+        cplx af[CU_LA + 1][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) af[0][a] = ab[a * 16 * CU_AP];
+        for (int l = 0; l < CU_LA; ++l)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[l][a] = ab[a * 16 * CU_AP + l * 4];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const int cur = ks & 1;
+            const int cur = ks % (CU_LA + 1);
             if (ks == 2) {
                 // the requests for row block ib+1 and the stores of row block ib-1 are issued HERE, behind the first
                 // matrix instructions: a wave issues them in the shadow of its matrix instructions, not in front of them
@@ -1237,10 +1241,11 @@ __global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
                 if (ib > 0) store_block(ib - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ks + 1 < 16) {
+            if (ks + CU_LA < 16) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) af[cur ^ 1][a] = ab[a * 16 * CU_AP + (ks + 1) * 4];
+                for (int a = 0; a < 2; ++a) af[(ks + CU_LA) % (CU_LA + 1)][a] = ab[a * 16 * CU_AP + (ks + CU_LA) * 4];
             }
+            __builtin_amdgcn_sched_barrier(0);
             const double qs = qf[ks].x + qf[ks].y;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -1248,6 +1253,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
                 cs[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].y, qf[ks].y, cs[a], 0, 0, 0);
                 ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x + af[cur][a].y, qs, ci[a], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -1370,31 +1376,32 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
         }
         const cplx* abA = &As2[buf][0][fi * CU_AP + fk];
         const cplx* abB = &As2[buf][1][fi * CU_AP + fk];
-        cplx af[2];
-        af[0] = abA[0];
+        // The A fragments come from LDS CU2_LA k-steps ahead of the matrix instructions that use them, and the scheduling
+        // barriers keep them there: left to itself the compiler sinks every ds_read to just in front of its first use (the
+        // registers are full: both Q sets), and a wave then waits an LDS round trip per two k-steps with its matrix pipe idle
+        // (round-5 ISA: "ds_read x 2; s_waitcnt lgkmcnt(1); mfma" -- 64 % of the 3M matrix peak).
+        constexpr int CU2_LA = 2;
+        auto opA = [&](int ks) __attribute__((always_inline)) { return ks < 16 ? abA[ks * 4] : abB[(ks - 16) * 4]; };
+        cplx af[CU2_LA + 1];
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int cur = ks & 1;
+        for (int l = 0; l < CU2_LA; ++l) af[l] = opA(l);
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
             if (ks == 2) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (ib + 1 < nrb) { fetch_a(ib + 1, buf ^ 1); fetch_c(ib + 1); }
                 if (ib > 0) store_block(ib - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            af[cur ^ 1] = ks + 1 < 16 ? abA[(ks + 1) * 4] : abB[0];
-            const double qs = qfA[ks].x + qfA[ks].y;
-            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x, qfA[ks].x, cr, 0, 0, 0);
-            cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].y, qfA[ks].y, cs, 0, 0, 0);
-            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x + af[cur].y, qs, ci, 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const int cur = ks & 1;
-            if (ks + 1 < 16) af[cur ^ 1] = abB[(ks + 1) * 4];
-            const double qs = qfB[ks].x + qfB[ks].y;
-            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x, qfB[ks].x, cr, 0, 0, 0);
-            cs = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].y, qfB[ks].y, cs, 0, 0, 0);
-            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur].x + af[cur].y, qs, ci, 0, 0, 0);
+            if (ks + CU2_LA < 32) af[(ks + CU2_LA) % (CU2_LA + 1)] = opA(ks + CU2_LA);
+            __builtin_amdgcn_sched_barrier(0);
+            const cplx a = af[ks % (CU2_LA + 1)];
+            const cplx q = ks < 16 ? qfA[ks & 15] : qfB[ks & 15];
+            const double qs = q.x + q.y;
+            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, q.x, cr, 0, 0, 0);
+            cs = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, q.y, cs, 0, 0, 0);
+            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, qs, ci, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sr[r] = cr[r] - cs[r]; si[r] = ci[r] - cr[r] - cs[r]; }

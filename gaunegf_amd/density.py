@@ -70,7 +70,7 @@ SPECULATIVE_POINTS = 64      # new nodes evaluated per launch AHEAD of the conve
 SPECULATIVE_POINTS_ONE_CU = 192  # ... for systems whose inverse is ONE workgroup per matrix (n <= 256): up to one matrix
                                  # per compute unit a launch takes what a single matrix does (n = 200: 2 points 0.61 ms,
                                  # 108 points 0.68 ms, 324 points 1.44 ms) -- levels 2 ... 162 in one go
-SPECULATIVE_POINTS_SMALL = 512   # ... and for n <= 96 (matrix in registers, several per compute unit; n = 60: 2 points
+SPECULATIVE_POINTS_SMALL = int(os.environ.get("NEGF_SPECULATIVE_SMALL", "512"))   # ... and for n <= 96 (matrix in registers, several per compute unit; n = 60: 2 points
                                  # 93 us, 324 points 132 us): every level of the rule, 486 points, in one go
 
 

@@ -45,6 +45,12 @@ for r in rows[:10]:
     print(f"{r['Name'][:100]:100s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} avg_us {float(r['AverageNs'])/1e3:9.1f} {r['Percentage']}%")
 PY
        find gpurun_out/r5_skstats -name "*.db" -delete; find gpurun_out/r5_skstats -name "*trace.csv" -delete ;;
+    hostprof) for c in c4 c5; do timeout -k 10 600 python -m cProfile -o gpurun_out/r5_${c}_share8.prof bench.py --config $c --emulate-share 8 --steps 5 --no-cpu > gpurun_out/r5_${c}_share8_prof.json 2> gpurun_out/r5_${c}_share8_prof.err || exit 1
+         python - <<PY
+import pstats
+p = pstats.Stats("gpurun_out/r5_${c}_share8.prof"); p.sort_stats("cumulative").print_stats(45)
+PY
+       done > gpurun_out/r5_hostprof.log 2>&1; grep -E "ms_per_step" gpurun_out/r5_c4_share8_prof.json | cut -c1-200; tail -130 gpurun_out/r5_hostprof.log ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
