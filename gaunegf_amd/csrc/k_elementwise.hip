@@ -244,6 +244,44 @@ __global__ __launch_bounds__(EW_THREADS) void accumulate_final_kernel(
     acc[i] = a;
 }
 
+// The same reduction over matrices that the windowed inverse left in their reduced form (rows never moved: G[i][j] =
+// W[pivrow[i]][colof[j]]): the weighted sum of GrInt needs no G, so the gather pass (read + write of every matrix) and the
+// re-read by accumulate_partial_kernel become ONE read through the permutation.  Same chunks, same order of additions.
+__global__ __launch_bounds__(EW_THREADS) void accumulate_perm_partial_kernel(
+    int n, int nb, const cplx* __restrict__ w, const cplx* __restrict__ W, const int* __restrict__ piv,
+    const int* __restrict__ info, cplx* __restrict__ part)
+{
+    const int n2 = n * n;
+    const int i = blockIdx.x * EW_THREADS + threadIdx.x;
+    const int b0 = blockIdx.y * ACC_CHUNK, b1 = min(nb, b0 + ACC_CHUNK);
+    if (i >= n2) return;
+    const int r = i / n, cj = i - r * n;
+    const double qnan = __builtin_nan("");
+    cplx a = cmake(0.0, 0.0);
+    auto elem = [&](int b) {
+        if (info[b] != 0) return cmake(qnan, qnan);                       // (uniform; a dead matrix's bookkeeping is not an index)
+        const int* pb = piv + (size_t)b * 2 * n;
+        return W[(size_t)b * n2 + (size_t)pb[r] * n + pb[n + cj]];
+    };
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        const cplx x0 = elem(b), x1 = elem(b + 1), x2 = elem(b + 2), x3 = elem(b + 3);
+        a = cfma(a, w[b + 0], x0); a = cfma(a, w[b + 1], x1);
+        a = cfma(a, w[b + 2], x2); a = cfma(a, w[b + 3], x3);
+    }
+    for (; b < b1; ++b) a = cfma(a, w[b], elem(b));
+    part[(size_t)blockIdx.y * n2 + i] = a;
+}
+
+void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const cplx* W, const int* piv, const int* info, cplx* acc, cplx* part)
+{
+    const int n2 = n * n;
+    const int g = (n2 + EW_THREADS - 1) / EW_THREADS;
+    const int nchunks = (nb + ACC_CHUNK - 1) / ACC_CHUNK;
+    hipLaunchKernelGGL(accumulate_perm_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n, nb, w, W, piv, info, part);
+    hipLaunchKernelGGL(accumulate_final_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nchunks, part, acc);
+}
+
 // `part` must hold ceil(nb / ACC_CHUNK) * n2 elements
 size_t accumulate_scratch_elems(int n2, int nb) { return (size_t)((nb + ACC_CHUNK - 1) / ACC_CHUNK) * n2; }
 

@@ -1438,7 +1438,7 @@ __global__ void gj_state_init_kernel(int n, int* __restrict__ piv_all, int* __re
 double g_gj_vector_flops = 0;            // 3M-equivalent flops of the last launch that ran as VECTOR work (strip window kernels)
 
 template <int NBI, int RPT>
-void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp, int win_mode)
+void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* sdp, int win_mode, bool skip_gather)
 {
     const size_t smem = (size_t)(2 * PW * NBI + 2 * NBI * WIN) * sizeof(cplx);      // candidate rows + Q of two sub-panels
     auto kern = gj_window_kernel<NBI, RPT>;
@@ -1548,8 +1548,11 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
             window(c0, cw);
             if (nblk > 1) colupdate(c0, cw, -1);
         }
-        hipLaunchKernelGGL(gj_gather_kernel, dim3(n, count), dim3(256), 0, s, n, (const cplx*)Ag, Bg, stride,
-                           (const int*)pg, (const int*)ig);
+        // (skip_gather: the caller resolves G[i][j] = W[pivrow[i]][colof[j]] itself -- the weighted sum of GrInt reads the
+        //  reduced matrices through the permutation, launch_accumulate_perm, and G is never written)
+        if (!skip_gather)
+            hipLaunchKernelGGL(gj_gather_kernel, dim3(n, count), dim3(256), 0, s, n, (const cplx*)Ag, Bg, stride,
+                               (const int*)pg, (const int*)ig);
     };
     // Small batches -- what the energy grid of BASELINE's multi-GPU configurations leaves one GPU: C4 sharded 8
     // ways is 61 matrices of N = 800, C5 128 of N = 1000 -- cannot cover the chip with one panel workgroup per
@@ -1647,7 +1650,8 @@ bool inverse_blocked_supported(int n) { return gj_pick(n) != 0 || gj_large_pick(
 // Returns true: the result is in B.
 double inverse_blocked_vector_flops() { return g_gj_vector_flops; }
 
-bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* side, int win_mode)
+bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info, GjSideStreams* side, int win_mode,
+                            bool* skip_gather)
 {
     g_gj_vector_flops = 0;
     // single-workgroup kernel up to 256 rows (its 32-column panel configuration); above, the windowed
@@ -1661,15 +1665,18 @@ bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, siz
     // win_mode 1 (tests, A/B) takes the windowed path with the strip kernel wherever it exists (64 <= n), win_mode 2 the
     // pre-strip configuration (single workgroup up to 256, team window kernels above)
     const bool single_wg = win_mode == 1 ? n < 64 : win_mode == 2 ? n <= 256 : n < large_min;
+    const bool defer = skip_gather && *skip_gather;               // only the windowed path can leave the gather to the caller
+    if (skip_gather) *skip_gather = false;
     if (single_wg && gj_pick(n) == 1) { gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true; }
+    if (defer && gj_large_pick(n) != 0) *skip_gather = true;
     // sub-panels of 16 columns up to n = 1024 (measured on MI355X, 1000 matrices: n = 500 46.2 -> 41.1 ms,
     // n = 1000 296 -> 257 ms against sub-panels of 8: half as many passes over the 64-column window)
     switch (gj_large_pick(n)) {
-    case 1: gj_large_launch<16, 2>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
-    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
-    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
-    case 4: gj_large_launch<16, 1>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
-    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info, side, win_mode); return true;
+    case 1: gj_large_launch<16, 2>(st, n, nb, A, B, stride, piv, info, side, win_mode, defer); return true;
+    case 2: gj_large_launch<8, 4>(st, n, nb, A, B, stride, piv, info, side, win_mode, defer); return true;
+    case 3: gj_large_launch<4, 8>(st, n, nb, A, B, stride, piv, info, side, win_mode, defer); return true;
+    case 4: gj_large_launch<16, 1>(st, n, nb, A, B, stride, piv, info, side, win_mode, defer); return true;
+    case 5: gj_large_launch<2, 16>(st, n, nb, A, B, stride, piv, info, side, win_mode, defer); return true;
     default: return false;
     }
 }

@@ -394,13 +394,16 @@ int run_inverse(negf_ctx* c, int nb, int* info)
 {
     ProfScope ps(c, "inverse");
     int algo = c->inverse_algo;
+    c->G_deferred = false;
     if (algo == 0) algo = inverse_blocked_supported(c->n) ? 2 : 1;
     const int win_mode = algo == 3 ? 1 : algo == 4 ? 2 : 0;      // 3 / 4: the blocked path with the window kernel chosen
     if (algo > 2) algo = 2;
     bool in_b = false;
     if (algo == 2) {
         // false: no blocked kernel serves this n (nothing was launched) -> the unblocked kernel
-        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info, &c->gj_side, win_mode);
+        bool skip = c->defer_gather;
+        in_b = launch_inverse_blocked(c->stream, c->n, nb, c->d_A, c->d_T1, (size_t)c->n * c->n, c->d_ipiv, info, &c->gj_side, win_mode, &skip);
+        c->G_deferred = skip;
         if (!in_b) algo = 1;
     }
     if (algo == 1 && !launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info)) return NEGF_EINVAL;
@@ -1182,9 +1185,18 @@ int negf_gr_int_dev(negf_ctx* c, int handle, int m, const double* E_dev, const d
     NEGF_HIP_CHECK(hipMemsetAsync(out, 0, n2 * sizeof(cplx), c->stream));
     for (int m0 = 0; m0 < m; m0 += c->batch) {
         const int nb = std::min(c->batch, m - m0);
-        if ((rc = run_assemble_inverse(c, p, m0, nb, E))) return rc;
+        // the weighted sum needs no G: the windowed inverse leaves its gather out and the sum reads the reduced matrices
+        // through the pivot bookkeeping (NEGF_GATHER_FUSED=0: the gather + accumulate sequence)
+        static int fused = -1;
+        if (fused < 0) { const char* e = getenv("NEGF_GATHER_FUSED"); fused = e ? atoi(e) : 1; }
+        c->defer_gather = fused != 0;
+        rc = run_assemble_inverse(c, p, m0, nb, E);
+        c->defer_gather = false;
+        if (rc) return rc;
         ProfScope ps(c, "accumulate");
-        launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out, c->W2);
+        if (c->G_deferred) launch_accumulate_perm(c->stream, c->n, nb, w + m0, c->W1, c->d_ipiv, c->d_info + m0, out, c->W2);
+        else launch_accumulate(c->stream, (int)n2, nb, w + m0, c->G, out, c->W2);
+        c->G_deferred = false;
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());

@@ -212,6 +212,8 @@ struct negf_ctx {
     double* d_scal = nullptr;      // [m_cap][8] scalar outputs
     double* d_site = nullptr;      // [batch][n] per-site DOS staging
     bool gcache_pinned = false;    // a launch holds a pointer to one of the entries: allocation failures elsewhere must not drop the cache
+    bool defer_gather = false;     // negf_gr_int: the weighted sum reads the reduced matrices through the permutation (set around run_assemble_inverse)
+    bool G_deferred = false;       // ... and the last run_inverse did leave its result un-gathered in W1 (with d_ipiv)
     int inverse_algo = 0;
     int gamma_algo = 0;            // 0: compact Gamma products when the provider allows, 1: always dense
     cplx* d_gsmall = nullptr;      // small Gamma matrices of a batch (compact path)
@@ -264,8 +266,11 @@ bool launch_inverse_unblocked(hipStream_t st, int n, int nb, cplx* A, int* info)
 // inverses end up in B, false when in A
 // win_mode: 0 = the measured choice of window kernel per size and batch, 1 = the strip window kernel (gj_strip.h)
 // wherever it exists, 2 = the pre-strip kernels (negf_set_inverse_algo 3 / 4)
+// skip_gather (in / out): in = the caller can read the reduced matrices through the pivot bookkeeping itself
+// (G[i][j] = A[pivrow[i]][colof[j]], piv = [nb][2][n]); out = the gather was left out (windowed path only) -- the return
+// value then still says "B", but B was not written
 bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t stride, int* piv, int* info,
-                            GjSideStreams* side = nullptr, int win_mode = 0);
+                            GjSideStreams* side = nullptr, int win_mode = 0, bool* skip_gather = nullptr);
 bool inverse_blocked_supported(int n);
 // of the last launch_inverse_blocked: the part of its 6 n np^2 three-real-product flops that ran on the VECTOR pipe
 // (the register-strip window kernels), i.e. was not issued to the matrix cores
@@ -274,6 +279,9 @@ double inverse_blocked_vector_flops();
 // acc += sum_b w[b] * X[b]   (fixed summation order, deterministic); `part` is scratch of
 // accumulate_scratch_elems(n2, nb) elements (<= nb * n2 / 32)
 void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx* X, cplx* acc, cplx* part);
+// the same sum over matrices still in their reduced, un-gathered form: X[b][i][j] = W[b][pivrow_b[i]][colof_b[j]] (piv = [nb][2][n];
+// a matrix with info[b] != 0 counts as NaN, as its gathered form would)
+void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const cplx* W, const int* piv, const int* info, cplx* acc, cplx* part);
 void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cplx* out);
 size_t accumulate_scratch_elems(int n2, int nb);
 

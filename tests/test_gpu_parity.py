@@ -162,6 +162,34 @@ def test_singular_and_nan_matrices_by_window_kernel(engine, N, algo):
         engine.set_inverse_algo(0)
 
 
+@pytest.mark.parametrize("N,M", [(230, 70), (300, 40), (333, 37), (650, 9)])
+def test_GrInt_reads_the_windowed_inverse_through_its_permutation(engine, N, M):
+    """GrInt on the windowed path never writes G: the inverse leaves its gather out and the weighted sum reads the reduced
+    matrices through the pivot bookkeeping (launch_accumulate_perm; same chunks, same order of additions as the
+    gather + accumulate sequence).  Against the oracle, against the weighted sum of the G(E) that GrBatch DOES gather
+    (1e-13: a host sum in another order), run-to-run bitwise, and with a singular energy in the batch: NaN result,
+    info at that energy only."""
+    from gaunegf_amd.integrate import GrBatch, GrInt
+    F, S, g_dev, g_ref = _const_provider(N, 700 + N, nc=20)
+    E = np.linspace(-2.5, 2.5, M) + 0.03j
+    w = (np.cos(np.arange(M)) + 1.5) / M * (1 + 0.3j)
+    got = GrInt(F, S, g_dev, E, w)
+    assert rel_fro(got, oracle.GrInt(F, S, g_ref, E, w)) < TOL
+    G = GrBatch(F, S, g_dev, E)
+    assert rel_fro(got, np.tensordot(w, G, axes=(0, 0))) < 1e-13
+    assert np.array_equal(got, GrInt(F, S, g_dev, E, w))
+
+    class Probe:                          # Sigma = 0 and F = S (a full matrix: no spin-block split): E = 1 makes E S - F == 0
+        def sigmaTot(self, E_): return np.zeros((N, N), dtype=complex)
+        def sigma(self, E_, i): return np.zeros((N, N), dtype=complex)
+    Es = np.array([0.5 + 0.1j, 1.0 + 0j, 2.0 + 0.1j])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        bad = GrInt(S, S, Probe(), Es, np.ones(3, dtype=complex))
+    assert np.all(np.isnan(bad)) and any("singular" in str(r.message) for r in rec)
+    assert engine.last_info[1] != 0 and engine.last_info[0] == 0 and engine.last_info[2] == 0
+
+
 @pytest.mark.parametrize("N,M", [(300, 480), (449, 640)])
 def test_windowed_inverse_large_batches(engine, N, M):
     """Batches large enough for the throughput configuration of the windowed inverse: four stream groups of >= 120
