@@ -273,12 +273,65 @@ __global__ __launch_bounds__(EW_THREADS) void accumulate_perm_partial_kernel(
     part[(size_t)blockIdx.y * n2 + i] = a;
 }
 
+// Row form (n <= 2048): a workgroup owns ONE output row i of one chunk of energies.  Row pivrow_b[i] of matrix b is read as what it
+// is -- n contiguous elements -- into LDS (double buffered: the next matrix's row is in flight while this one is used) and the
+// column permutation is resolved there: out[i][j] += w_b row[colof_b[j]].  The element form above reads 2.2 x the bytes (PMC: 8.9
+// GB per 1000 x n = 500 against 4.0) because its gathers use a quarter or half of every cache line they touch per wave.
+static constexpr int APR_MAXN = 2048;
+__global__ __launch_bounds__(EW_THREADS) void accumulate_perm_rows_kernel(
+    int n, int nb, const cplx* __restrict__ w, const cplx* __restrict__ W, const int* __restrict__ piv,
+    const int* __restrict__ info, cplx* __restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char apr_raw[];
+    cplx* rowbuf = reinterpret_cast<cplx*>(apr_raw);                      // [2][n]
+    const int i = blockIdx.x, n2 = n * n;
+    const int b0 = blockIdx.y * ACC_CHUNK, b1 = min(nb, b0 + ACC_CHUNK);
+    const int tid = threadIdx.x;
+    constexpr int CPT = APR_MAXN / EW_THREADS;                            // columns per thread
+    const double qnan = __builtin_nan("");
+    cplx acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = cmake(0.0, 0.0);
+    auto fetch = [&](int b, int buf) {
+        if (info[b] != 0) return;                                         // (uniform; a dead matrix's bookkeeping is not an index)
+        const cplx* src = W + (size_t)b * n2 + (size_t)piv[(size_t)b * 2 * n + i] * n;
+        for (int j = tid; j < n; j += EW_THREADS) rowbuf[buf * n + j] = src[j];
+    };
+    fetch(b0, 0);
+    for (int b = b0; b < b1; ++b) {
+        const int buf = (b - b0) & 1;
+        __syncthreads();                                                  // row b is in LDS; everybody is done with the other buffer
+        if (b + 1 < b1) fetch(b + 1, buf ^ 1);
+        const bool dead = info[b] != 0;
+        const int* cf = piv + (size_t)b * 2 * n + n;
+        const cplx wb = w[b];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int j = tid + c * EW_THREADS;
+            if (j < n) {
+                const cplx x = dead ? cmake(qnan, qnan) : rowbuf[buf * n + cf[j]];
+                acc[c] = cfma(acc[c], wb, x);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int j = tid + c * EW_THREADS;
+        if (j < n) part[(size_t)blockIdx.y * n2 + (size_t)i * n + j] = acc[c];
+    }
+}
+
 void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const cplx* W, const int* piv, const int* info, cplx* acc, cplx* part)
 {
     const int n2 = n * n;
     const int g = (n2 + EW_THREADS - 1) / EW_THREADS;
     const int nchunks = (nb + ACC_CHUNK - 1) / ACC_CHUNK;
-    hipLaunchKernelGGL(accumulate_perm_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n, nb, w, W, piv, info, part);
+    static int rows = -1;
+    if (rows < 0) { const char* e = getenv("NEGF_ACC_PERM_ROWS"); rows = e ? atoi(e) : 1; }
+    if (rows && n <= APR_MAXN)
+        hipLaunchKernelGGL(accumulate_perm_rows_kernel, dim3(n, nchunks), dim3(EW_THREADS), (size_t)2 * n * sizeof(cplx), st, n, nb, w, W, piv, info, part);
+    else
+        hipLaunchKernelGGL(accumulate_perm_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n, nb, w, W, piv, info, part);
     hipLaunchKernelGGL(accumulate_final_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nchunks, part, acc);
 }
 
