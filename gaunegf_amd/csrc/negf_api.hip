@@ -844,11 +844,20 @@ static bool same_bytes(const void* a, const void* b, size_t bytes)
     const size_t chunk = (bytes + hw - 1) / hw;
     std::atomic<bool> same{true};
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < hw; ++t) {
-        const size_t lo = std::min(bytes, t * chunk), hi = std::min(bytes, lo + chunk);
-        th.emplace_back([&, lo, hi] { if (hi > lo && std::memcmp((const char*)a + lo, (const char*)b + lo, hi - lo) != 0) same = false; });
+    try {
+        for (unsigned t = 1; t < hw; ++t) {
+            const size_t lo = std::min(bytes, t * chunk), hi = std::min(bytes, lo + chunk);
+            if (hi <= lo) break;
+            th.emplace_back([&same, a, b, lo, hi] { if (std::memcmp((const char*)a + lo, (const char*)b + lo, hi - lo) != 0) same = false; });
+        }
+    } catch (...) {                                              // (no more threads: the rest is compared here)
     }
-    if (std::memcmp(a, b, std::min(bytes, chunk)) != 0) same = false;
+    const size_t mine_hi = std::min(bytes, chunk);
+    if (std::memcmp(a, b, mine_hi) != 0) same = false;
+    if (th.size() + 1 < hw) {                                    // chunks nobody took
+        const size_t lo = std::min(bytes, (th.size() + 1) * chunk);
+        if (lo < bytes && std::memcmp((const char*)a + lo, (const char*)b + lo, bytes - lo) != 0) same = false;
+    }
     for (auto& x : th) x.join();
     return same;
 }
