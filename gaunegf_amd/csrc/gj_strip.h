@@ -57,7 +57,9 @@ template <int RPL, int SW, int NW, int OCC, int PF /* chunks of 4 columns in fli
 __global__ __launch_bounds__(NW * 64, OCC) void gj_window_strip_kernel(
     int n, cplx* __restrict__ bufA, cplx* __restrict__ bufB /* unused */, size_t mat_stride, int* __restrict__ piv_all /* [nb][2][n]: pivrow, colof */, int* __restrict__ info, int c0, int cw,
     unsigned long long* __restrict__ stamps /* diagnostic (NEGF_GJ_STAMPS): workgroup 0, [sub-window][8]; nullptr in production */,
-    int dbg /* timing ablations (NEGF_GJ_STRIP_DBG; wrong results): 1 no forward FMAs, 2 no backward FMAs, 4 no pivot steps, 8 no backward */)
+    int dbg /* timing ablations (NEGF_GJ_STRIP_DBG; wrong results): 1 no forward FMAs, 2 no backward FMAs, 4 no pivot steps, 8 no
+               backward.  A RUN-TIME value on purpose: compiled out (constexpr 0) the uniform branches around the FMA blocks go away and
+               the register allocator hoists across them -- 1314 spilled registers instead of 3 (measured) */)
 {
     constexpr int T = NW * 64;
     constexpr int KMAX = WIN - SW;                   // columns of the window in front of its last sub-window

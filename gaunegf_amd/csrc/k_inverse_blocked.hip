@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
             }
         const cplx* ab = &As[buf][(wr + fi) * CU_AP + fk];
         // (A fragments two k-steps ahead of their matrix instructions, held there by scheduling barriers: see gj_colupdate2_kernel)
-        constexpr int CU_LA = 2;
+        constexpr int CU_LA = 1;
         cplx af[CU_LA + 1][2];
 #pragma unroll
         for (int l = 0; l < CU_LA; ++l)
@@ -1246,12 +1246,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gj_colupdate_kernel(
                 for (int a = 0; a < 2; ++a) af[(ks + CU_LA) % (CU_LA + 1)][a] = ab[a * 16 * CU_AP + (ks + CU_LA) * 4];
             }
             __builtin_amdgcn_sched_barrier(0);
-            const double qs = qf[ks].x + qf[ks].y;
+            if (ks * 4 < cw) {                                // (uniform: a ragged last window has fewer k-steps; its Q rows beyond are zero)
+                const double qs = qf[ks].x + qf[ks].y;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x, qf[ks].x, cr[a], 0, 0, 0);
-                cs[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].y, qf[ks].y, cs[a], 0, 0, 0);
-                ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x + af[cur][a].y, qs, ci[a], 0, 0, 0);
+                for (int a = 0; a < 2; ++a) {
+                    cr[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x, qf[ks].x, cr[a], 0, 0, 0);
+                    cs[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].y, qf[ks].y, cs[a], 0, 0, 0);
+                    ci[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][a].x + af[cur][a].y, qs, ci[a], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1381,6 +1383,7 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
         // registers are full: both Q sets), and a wave then waits an LDS round trip per two k-steps with its matrix pipe idle
         // (round-5 ISA: "ds_read x 2; s_waitcnt lgkmcnt(1); mfma" -- 64 % of the 3M matrix peak).
         constexpr int CU2_LA = 2;
+        const int ksB = (cwB + 3) >> 2;
         auto opA = [&](int ks) __attribute__((always_inline)) { return ks < 16 ? abA[ks * 4] : abB[(ks - 16) * 4]; };
         cplx af[CU2_LA + 1];
 #pragma unroll
@@ -1395,12 +1398,14 @@ __global__ __launch_bounds__(CU_THREADS, 2) void gj_colupdate2_kernel(
             }
             if (ks + CU2_LA < 32) af[(ks + CU2_LA) % (CU2_LA + 1)] = opA(ks + CU2_LA);
             __builtin_amdgcn_sched_barrier(0);
-            const cplx a = af[ks % (CU2_LA + 1)];
-            const cplx q = ks < 16 ? qfA[ks & 15] : qfB[ks & 15];
-            const double qs = q.x + q.y;
-            cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, q.x, cr, 0, 0, 0);
-            cs = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, q.y, cs, 0, 0, 0);
-            ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, qs, ci, 0, 0, 0);
+            if (ks < 16 || ks - 16 < ksB) {                  // (uniform: a ragged last window B has fewer k-steps; its Q rows beyond are zero)
+                const cplx a = af[ks % (CU2_LA + 1)];
+                const cplx q = ks < 16 ? qfA[ks & 15] : qfB[ks & 15];
+                const double qs = q.x + q.y;
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, q.x, cr, 0, 0, 0);
+                cs = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, q.y, cs, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x + a.y, qs, ci, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1664,7 +1669,13 @@ bool launch_inverse_blocked(hipStream_t st, int n, int nb, cplx* A, cplx* B, siz
     if (large_min < 0) { const char* e = getenv("NEGF_GJ_LARGE_MIN"); large_min = e ? atoi(e) : 209; }
     // win_mode 1 (tests, A/B) takes the windowed path with the strip kernel wherever it exists (64 <= n), win_mode 2 the
     // pre-strip configuration (single workgroup up to 256, team window kernels above)
-    const bool single_wg = win_mode == 1 ? n < 64 : win_mode == 2 ? n <= 256 : n < large_min;
+    // (below large_min the single-workgroup kernel keeps the batches that do not fill the chip -- one matrix per CU costs what a
+    // single matrix does: 108 x n = 200 0.65 ms against 0.94 windowed -- and the windowed path takes the rest, ms per 1000
+    // matrices windowed / single workgroup: n = 100 0.87 / 0.93, 128 1.09 / 1.29, 160 1.60 / 1.83, 192 2.21 / 2.60,
+    // 200 2.67 / 2.97 (C2), 208 2.66 / 3.09; 324 x n = 200 1.26 / 1.36)
+    static int small_win_min = -1;       // matrices from which 100 <= n < large_min goes windowed
+    if (small_win_min < 0) { const char* e = getenv("NEGF_GJ_SMALL_WIN_MIN"); small_win_min = e ? atoi(e) : 257; }
+    const bool single_wg = win_mode == 1 ? n < 64 : win_mode == 2 ? n <= 256 : (n < large_min && !(n >= 100 && nb >= small_win_min));
     const bool defer = skip_gather && *skip_gather;               // only the windowed path can leave the gather to the caller
     if (skip_gather) *skip_gather = false;
     if (single_wg && gj_pick(n) == 1) { gj_launch<CfgSplit>(st, n, nb, A, B, stride, info); return true; }

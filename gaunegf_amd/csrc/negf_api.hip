@@ -409,9 +409,10 @@ int run_inverse(negf_ctx* c, int nb, int* info)
     if (algo == 1 && !launch_inverse_unblocked(c->stream, c->n, nb, c->d_A, info)) return NEGF_EINVAL;
     NEGF_HIP_CHECK(hipGetLastError());
     {   // 8 n^3 algorithmic; the blocked kernels run every rank-NB update on the matrix cores in 3M form over
-        // 16-granular tiles (the pivot steps themselves are vector work), the unblocked kernel none of it
-        const double n = c->n, np = (double)((c->n + 15) & ~15);
-        negf_count_flops(8.0 * n * n * n * nb, algo == 2 ? 6.0 * n * np * np * nb - inverse_blocked_vector_flops() : 0.0);
+        // 16-granular tiles with K in steps of four (the zero k-steps of a ragged last window are skipped); the pivot steps
+        // themselves are vector work, and so is everything the strip window kernels do; the unblocked kernel issues none
+        const double n = c->n, np = (double)((c->n + 15) & ~15), k4 = (double)((c->n + 3) & ~3);
+        negf_count_flops(8.0 * n * n * n * nb, algo == 2 ? 6.0 * np * np * k4 * nb - inverse_blocked_vector_flops() : 0.0);
     }
     c->G = in_b ? c->d_T1 : c->d_A;
     c->W1 = in_b ? c->d_A : c->d_T1;

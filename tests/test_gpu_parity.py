@@ -190,9 +190,11 @@ def test_GrInt_reads_the_windowed_inverse_through_its_permutation(engine, N, M):
     assert engine.last_info[1] != 0 and engine.last_info[0] == 0 and engine.last_info[2] == 0
 
 
-@pytest.mark.parametrize("N,M", [(300, 480), (449, 640)])
+@pytest.mark.parametrize("N,M", [(300, 480), (449, 640), (150, 300), (200, 520)])
 def test_windowed_inverse_large_batches(engine, N, M):
-    """Batches large enough for the throughput configuration of the windowed inverse: four stream groups of >= 120
+    """(N = 150, 200: below the switch-over dimension the windowed path takes the batches of more matrices than the chip
+    has CUs -- the C2-sized systems at full batch -- and the single-workgroup kernel the rest.)
+    Batches large enough for the throughput configuration of the windowed inverse: four stream groups of >= 120
     matrices, windows in PAIRS (fused update kernel, two lean workgroups per CU) and the lean single-window update
     -- small batches run the windows one by one with eight-wave workgroups.  N = 300: two pairs and an odd last window of
     44 columns; N = 449: four pairs, the last window one column wide.  Checked through the weighted sum over all
