@@ -1480,7 +1480,9 @@ void gj_large_launch(hipStream_t st, int n, int nb, cplx* A, cplx* B, size_t str
     static int pair = -1;                // windows in pairs (one pass over the other column blocks per pair); 0: one by one
     if (pair < 0) { const char* e = getenv("NEGF_GJ_PAIR"); pair = e ? atoi(e) : 1; }
     static long pair_min = -1, fat_max = -1, fat_total_max = -1;
-    if (pair_min < 0) { const char* e = getenv("NEGF_GJ_PAIR_MIN"); pair_min = e ? atol(e) : 352; }
+    // (round 5, with the strip window kernels, inverse ms without / with pairs: 122 x N = 800 (330 workgroups per group) 13.46 /
+    //  12.09, 128 x N = 500 (192) 3.93 / 3.94, 61 x N = 800 (165) 7.39 / 8.95: the threshold moved from 352 to 256)
+    if (pair_min < 0) { const char* e = getenv("NEGF_GJ_PAIR_MIN"); pair_min = e ? atol(e) : 256; }
     if (fat_max < 0) { const char* e = getenv("NEGF_GJ_FAT_MAX"); fat_max = e ? atol(e) : 256; }
     if (fat_total_max < 0) { const char* e = getenv("NEGF_GJ_FAT_TOTAL_MAX"); fat_total_max = e ? atol(e) : 2000; }
     const int nblk = (n + 63) / 64;
