@@ -153,13 +153,14 @@ class Engine:
         if a.dtype == np.complex128 and a.flags.c_contiguous:
             return a                                              # (nothing to convert)
         cache = self.__dict__.setdefault("_sys_conv", [])
+        frozen = (not a.flags.writeable) and a.base is None       # an owned read-only array (integrate._split_blocks): cannot change
         for k, (src, snap, conv) in enumerate(cache):
-            if src is a and snap.shape == a.shape and snap.dtype == a.dtype and np.array_equal(a, snap):
+            if src is a and (snap is None or (snap.shape == a.shape and snap.dtype == a.dtype and np.array_equal(a, snap))):
                 cache.append(cache.pop(k))
                 return conv
         conv = _c128(a)
         if 128 * 128 <= a.size and a.nbytes <= (64 << 20):        # (small: the conversion costs less than the comparison; large: not worth the host memory)
-            cache.append((a, a.copy(), conv))
+            cache.append((a, None if frozen else a.copy(), conv))
             del cache[:-4]
         return conv
 

@@ -116,6 +116,34 @@ class _SpinBlockView:
         return self._block(("c", complex(E), i), lambda: self.g.sigma(E, i))
 
 
+_SPLIT_BLOCKS = {}        # the blocks of the last block-diagonal system: key (id, shape, dtype, fingerprint) of F and S
+
+
+def _split_blocks(F, S, N):
+    """(F_aa, S_aa, F_bb, S_bb) as contiguous READ-ONLY copies when F, S are exactly block diagonal, else None.  A front-end
+    that alternates between two entry points on one system (GrLessInt, calculate_transmission, ...) hands the same 2N x 2N
+    arrays over again and again: scanning the off-diagonal blocks, copying the diagonal ones and converting them to
+    complex was 20 ms per entry point at N = 1000 (38 of the 148 ms of a per-GPU share of BASELINE C5).  The answer is kept
+    for the last system, recognised by object identity AND a checksum of its bytes (a caller may have changed it in place);
+    the blocks are read-only, so the engine keeps their complex conversions without comparing contents."""
+    from .engine import fingerprint
+    key = None
+    if F.flags.c_contiguous and S.flags.c_contiguous:
+        key = (id(F), id(S), F.shape, F.dtype.str, S.dtype.str, fingerprint(F), fingerprint(S))
+        hit = _SPLIT_BLOCKS.get("last")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    n2 = F.shape[0]
+    blocks = None
+    if not any(np.any(M[:N, N:]) or np.any(M[N:, :N]) for M in (F, S)):
+        blocks = tuple(np.ascontiguousarray(M[sl, sl]) for sl in (slice(0, N), slice(N, n2)) for M in (F, S))
+        for b in blocks:
+            b.setflags(write=False)
+    if key is not None:
+        _SPLIT_BLOCKS["last"] = (key, blocks)
+    return blocks
+
+
 def _spin_split(F, S, g):
     """[(slice, F_block, S_block, g_block)] * 2 when F, S are exactly block diagonal 2N x 2N matrices and
     the provider can serve the blocks separately; None otherwise.  Two N-sized solves then replace the
@@ -125,20 +153,22 @@ def _spin_split(F, S, g):
     if not SPIN_BLOCK_SPLIT or n2 % 2 or n2 < 4:
         return None
     N = n2 // 2
-    for M in (F, S):
-        if np.any(M[:N, N:]) or np.any(M[N:, :N]):
-            return None
     sls = (slice(0, N), slice(N, n2))
+    if hasattr(g, "_negf_spin_split"):
+        pass
+    elif hasattr(g, "_negf_lower"):
+        return None                                   # device-side provider defined on the 2N space
+    blocks = _split_blocks(F, S, N)
+    if blocks is None:
+        return None
     if hasattr(g, "_negf_spin_split"):
         halves = g._negf_spin_split(N)
         if halves is None:
             return None
-    elif hasattr(g, "_negf_lower"):
-        return None                                   # device-side provider defined on the 2N space
     else:
         cache = {}
         halves = [_SpinBlockView(g, N, sl, cache) for sl in sls]
-    return [(sl, F[sl, sl], S[sl, sl], h) for sl, h in zip(sls, halves)]
+    return [(sls[0], blocks[0], blocks[1], halves[0]), (sls[1], blocks[2], blocks[3], halves[1])]
 
 
 _split_depth = 0          # > 0 while the blocks of a split system are being integrated: split once, not recursively

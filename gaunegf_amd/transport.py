@@ -190,15 +190,14 @@ def _spinor_perm(N):
 
 def _spin_diagonal_blocks(F, S):
     """(F_uu, S_uu, F_dd, S_dd) when the 2N x 2N block-form matrices are EXACTLY block diagonal (the layout
-    scf.py:177-180 builds for 'u' / 'ro': blockdiag(alpha, beta)), else None."""
+    scf.py:177-180 builds for 'u' / 'ro': blockdiag(alpha, beta)), else None.  The blocks come from the same cache as the
+    integrals' (integrate._split_blocks: contiguous read-only copies, recognised by identity and checksum), so that
+    GrLessInt and calculate_transmission on one system share them and their complex conversions."""
     n2 = F.shape[0]
     if n2 % 2:
         return None
-    N = n2 // 2
-    for M in (F, S):
-        if np.any(M[:N, N:]) or np.any(M[N:, :N]):
-            return None
-    return F[:N, :N], S[:N, :N], F[N:, N:], S[N:, N:]
+    from .integrate import _split_blocks
+    return _split_blocks(F, S, n2 // 2)
 
 
 def _sigma_is_spin_expanded(sigma_calc, size):
