@@ -612,7 +612,7 @@ def run_api(config, steps, warmup, emulate_share, torch, dist, world, rank, loca
     from gaunegf_amd import distributed as D
     from gaunegf_amd import density as DN
     from gaunegf_amd.engine import get_engine
-    from gaunegf_amd.integrate import GrInt, GrLessInt
+    from gaunegf_amd.integrate import GrInt, GrIntSegments, GrLessInt
     if world > 1:
         D.enable()
     eng = get_engine()
@@ -627,11 +627,11 @@ def run_api(config, steps, warmup, emulate_share, torch, dist, world, rank, loca
         Er, wr = DN.real_axis_grid(-1e6, -8.0, 256, 0.0)
         pts_per_step = 742
         workload = ("C4: N_orb=800, Bethe-lattice Sigma (Au.bethe, 2 contacts x 3 atoms x 9 orbitals, eta=1e-6); one step = "
-                    "GrInt over the 486-point ANT contour + GrInt over the 256-point real-axis grid, the grid sharded "
-                    f"cyclically over {world} GPU(s), one sum all-reduce per integral")
+                    "the two GrInt sums of a density step -- 486-point ANT contour and 256-point real-axis grid -- as ONE pass "
+                    f"(GrIntSegments), the 742 energies dealt cyclically over {world} GPU(s), one all-reduce of both sums")
 
         def step():
-            return GrInt(F, S, g, Ec, wc), GrInt(F, S, g, Er, wr)
+            return tuple(GrIntSegments(F, S, g, [(Ec, wc), (Er, wr)]))
     else:
         from gaunegf_amd.matTools import formSigma
         from gaunegf_amd.surfGTester import surfGTest

@@ -56,6 +56,8 @@ SIGNATURES = {
     "negf_dos": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "negf_gr_int_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "negf_gless_int_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "negf_gr_int_seg_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
+    "negf_gless_int_seg_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     "negf_transmission_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "negf_sync": (C.c_int, [_vp]),
     "negf_last_info": (C.c_int, [_vp, C.c_int, _vp]),

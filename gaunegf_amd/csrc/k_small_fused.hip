@@ -480,6 +480,35 @@ __global__ __launch_bounds__(256) void small_reduce_kernel(int n2, int parts, co
     }
 }
 
+// the same for up to SEG_MAX segments in ONE launch (blockIdx.y = segment; an empty segment gets zeros): the twelve
+// level sums of a joint arc + tail refinement were twelve dependent launches behind a 90-us kernel
+constexpr int SEG_MAX = 32;
+struct SegEnds { int end[SEG_MAX]; };
+__global__ __launch_bounds__(256) void small_reduce_seg_kernel(int n2, SegEnds se, const cplx* __restrict__ partial,
+                                                               cplx* __restrict__ out)
+{
+    __shared__ cplx seg[8][32];
+    const int k = blockIdx.y;
+    const int start = k ? se.end[k - 1] : 0, parts = se.end[k] - start;
+    partial += (size_t)start * n2;
+    out += (size_t)k * n2;
+    const int el = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + el;
+    const int per = (parts + 7) / 8;
+    const int g0 = sg * per, g1 = min(parts, g0 + per);
+    cplx s = cmake(0.0, 0.0);
+    if (i < n2)
+        for (int g = g0; g < g1; ++g) s = cadd(s, partial[(size_t)g * n2 + i]);
+    seg[sg][el] = s;
+    __syncthreads();
+    if (sg == 0 && i < n2) {
+        cplx t = seg[0][el];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t = cadd(t, seg[q][el]);
+        out[i] = t;
+    }
+}
+
 template <int RPL, int CPW>
 void cw_launch(hipStream_t st, const SmallFusedArgs& a, int grid, size_t smem)
 {
@@ -544,7 +573,11 @@ void launch_small_fused(hipStream_t st, SmallFusedArgs a)
     }
     if (!a.Gout) {
         const int n2 = a.n * a.n;
-        if (a.nseg > 0) {
+        if (a.nseg > 1 && a.nseg <= SEG_MAX) {
+            SegEnds se;
+            for (int sg = 0; sg < SEG_MAX; ++sg) se.end[sg] = a.seg_end[std::min(sg, a.nseg - 1)];
+            hipLaunchKernelGGL(small_reduce_seg_kernel, dim3((n2 + 31) / 32, a.nseg), dim3(256), 0, st, n2, se, a.partial, a.out);
+        } else if (a.nseg > 0) {
             int start = 0;
             for (int sg = 0; sg < a.nseg; ++sg) {
                 const int end = a.seg_end[sg];

@@ -1493,27 +1493,19 @@ int negf_gr_int(negf_ctx* c, int handle, int m, const double* E, const double* w
 // (nested ANT levels 2, 6, 18, 54 ... of density.py:211-273; the doubling real-axis grids of :438-484) are served: the
 // levels a refinement is going to visit are evaluated together -- a level of 2 ... 36 points alone in a launch is pure
 // latency on this chip -- and handed back level by level.
-int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const double* w, int nseg,
-                    const int* seg_end, double* out, int* info)
+static int check_segments(int m, int nseg, const int* seg_end)
 {
-    SigmaProvider* p = get_provider(c, handle);
-    int rc = check_ready(c, p, m);
-    if (rc) return rc;
-    if (!out || nseg <= 0 || !seg_end || (m > 0 && (!E || !w))) return NEGF_EINVAL;
+    if (nseg <= 0 || !seg_end) return NEGF_EINVAL;
     for (int sg = 0, prev = 0; sg < nseg; ++sg) { if (seg_end[sg] < prev || seg_end[sg] > m) return NEGF_EINVAL; prev = seg_end[sg]; }
-    if (seg_end[nseg - 1] != m) return NEGF_EINVAL;
-    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    return seg_end[nseg - 1] == m ? NEGF_OK : NEGF_EINVAL;
+}
+
+// sum_m w_m G(E_m) per segment, everything on the device: Ed, wd [m], out [nseg][n*n]; seg_end is a host array
+static int gr_seg_core(negf_ctx* c, SigmaProvider* p, int m, const cplx* Ed, const cplx* wd, int nseg, const int* seg_end,
+                       cplx* out)
+{
+    int rc;
     const size_t n2 = (size_t)c->n * c->n;
-    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
-    // results: [nseg][n*n] on the device, then one download
-    if ((size_t)nseg * n2 > c->seg_out_cap) {
-        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
-        dev_free(c->d_seg_out); c->seg_out_cap = 0;
-        if ((rc = dev_alloc(&c->d_seg_out, (size_t)nseg * n2))) return rc;
-        c->seg_out_cap = (size_t)nseg * n2;
-    }
-    if ((rc = ensure_pinned(c, 2 * (size_t)m * sizeof(cplx) + nseg * n2 * sizeof(cplx) + (size_t)m * sizeof(int) + 64))) return rc;
-    const cplx* Ed = c->d_E; const cplx* wd = c->d_w;
     if (m > 0 && small_path(c, p) && m <= 4096) {
         const bool blocks = p->kind == SK_CHAIN1D || p->kind == SK_BETHE;
         if (blocks && (rc = ensure_blk(c, (size_t)m * p->blk_stride))) return rc;
@@ -1526,25 +1518,72 @@ int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const doubl
         if (blocks && (rc = run_sigma_blocks(c, p, m, Ed, c->d_iters, c->d_conv, 0))) return rc;
         ProfScope ps(c, "small");
         SmallFusedArgs a = small_args(c, p, 0, m, Ed);
-        a.w = wd; a.partial = c->d_small_part; a.out = c->d_seg_out; a.nseg = nseg; a.seg_end = seg_end;
+        a.w = wd; a.partial = c->d_small_part; a.out = out; a.nseg = nseg; a.seg_end = seg_end;
         launch_small_fused(c->stream, a);
         negf_count_flops(8.0 * c->n * (double)c->n * c->n * m, 0.0);
     } else {
         if ((rc = ensure_workspace(c, m, p->blk_stride))) return rc;
-        NEGF_HIP_CHECK(hipMemsetAsync(c->d_seg_out, 0, (size_t)nseg * n2 * sizeof(cplx), c->stream));
+        NEGF_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)nseg * n2 * sizeof(cplx), c->stream));
+        static int fused = -1;
+        if (fused < 0) { const char* e = getenv("NEGF_GATHER_FUSED"); fused = e ? atoi(e) : 1; }
         for (int m0 = 0; m0 < m; m0 += c->batch) {
             const int nb = std::min(c->batch, m - m0);
-            if ((rc = run_assemble_inverse(c, p, m0, nb, Ed))) return rc;
+            // (as in negf_gr_int_dev: the sums read the windowed inverse through its pivot bookkeeping, no gather)
+            c->defer_gather = fused != 0;
+            rc = run_assemble_inverse(c, p, m0, nb, Ed);
+            c->defer_gather = false;
+            if (rc) return rc;
+            const bool perm = c->G_deferred;
+            c->G_deferred = false;
             ProfScope ps(c, "accumulate");
             for (int sg = 0, start = 0; sg < nseg; start = seg_end[sg], ++sg) {
                 const int lo = std::max(start, m0), hi = std::min(seg_end[sg], m0 + nb);
-                if (hi > lo)
-                    launch_accumulate(c->stream, (int)n2, hi - lo, wd + lo, c->G + (size_t)(lo - m0) * n2, c->d_seg_out + (size_t)sg * n2, c->W2);
+                if (hi <= lo) continue;
+                if (perm)
+                    launch_accumulate_perm(c->stream, c->n, hi - lo, wd + lo, c->W1 + (size_t)(lo - m0) * n2,
+                                           c->d_ipiv + (size_t)(lo - m0) * 2 * c->n, c->d_info + lo, out + (size_t)sg * n2, c->W2);
+                else
+                    launch_accumulate(c->stream, (int)n2, hi - lo, wd + lo, c->G + (size_t)(lo - m0) * n2, out + (size_t)sg * n2, c->W2);
             }
         }
     }
     c->last_m = m;
     NEGF_HIP_CHECK(hipGetLastError());
+    return NEGF_OK;
+}
+
+int negf_gr_int_seg_dev(negf_ctx* c, int handle, int m, const double* E_dev, const double* w_dev, int nseg,
+                        const int* seg_end, double* out_dev)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out_dev || (m > 0 && (!E_dev || !w_dev)) || check_segments(m, nseg, seg_end)) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    if ((rc = ensure_mbuffers(c, m, p->n_contacts))) return rc;
+    return gr_seg_core(c, p, m, reinterpret_cast<const cplx*>(E_dev), reinterpret_cast<const cplx*>(w_dev), nseg, seg_end,
+                       reinterpret_cast<cplx*>(out_dev));
+}
+
+int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const double* w, int nseg,
+                    const int* seg_end, double* out, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out || (m > 0 && (!E || !w)) || check_segments(m, nseg, seg_end)) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
+    // results: [nseg][n*n] on the device, then one download
+    if ((size_t)nseg * n2 > c->seg_out_cap) {
+        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+        dev_free(c->d_seg_out); c->seg_out_cap = 0;
+        if ((rc = dev_alloc(&c->d_seg_out, (size_t)nseg * n2))) return rc;
+        c->seg_out_cap = (size_t)nseg * n2;
+    }
+    if ((rc = ensure_pinned(c, 2 * (size_t)m * sizeof(cplx) + nseg * n2 * sizeof(cplx) + (size_t)m * sizeof(int) + 64))) return rc;
+    if ((rc = gr_seg_core(c, p, m, c->d_E, c->d_w, nseg, seg_end, c->d_seg_out))) return rc;
     // one download of all segment sums and the info, one synchronisation
     unsigned char* pout = c->h_pin + 2 * (size_t)m * sizeof(cplx);
     int* pinfo = reinterpret_cast<int*>(pout + nseg * n2 * sizeof(cplx));
@@ -1564,9 +1603,7 @@ int negf_gless_int_seg(negf_ctx* c, int handle, int ind, int m, const double* E,
     SigmaProvider* p = get_provider(c, handle);
     int rc = check_ready(c, p, m);
     if (rc) return rc;
-    if (!out || nseg <= 0 || !seg_end || (m > 0 && (!E || !w))) return NEGF_EINVAL;
-    for (int sg = 0, prev = 0; sg < nseg; ++sg) { if (seg_end[sg] < prev || seg_end[sg] > m) return NEGF_EINVAL; prev = seg_end[sg]; }
-    if (seg_end[nseg - 1] != m) return NEGF_EINVAL;
+    if (!out || (m > 0 && (!E || !w)) || check_segments(m, nseg, seg_end)) return NEGF_EINVAL;
     const int contact = norm_contact(p, ind);
     if (contact == -2) return NEGF_EINVAL;
     NEGF_HIP_CHECK(hipSetDevice(c->device));
@@ -1589,6 +1626,20 @@ int negf_gless_int_seg(negf_ctx* c, int handle, int ind, int m, const double* E,
     rc = NEGF_OK;
     for (int i = 0; i < m; ++i) { if (info) info[i] = pinfo[i]; if (pinfo[i] != 0) rc = NEGF_ESINGULAR; }
     return rc;
+}
+
+int negf_gless_int_seg_dev(negf_ctx* c, int handle, int ind, int m, const double* E_dev, const double* w_dev, int nseg,
+                           const int* seg_end, double* out_dev)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!out_dev || (m > 0 && (!E_dev || !w_dev)) || check_segments(m, nseg, seg_end)) return NEGF_EINVAL;
+    const int contact = norm_contact(p, ind);
+    if (contact == -2) return NEGF_EINVAL;
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    return gless_core(c, p, contact, m, reinterpret_cast<const cplx*>(E_dev), reinterpret_cast<const cplx*>(w_dev),
+                      reinterpret_cast<cplx*>(out_dev), nseg, seg_end);
 }
 
 int negf_gless_int(negf_ctx* c, int handle, int ind, int m, const double* E, const double* w,

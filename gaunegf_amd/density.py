@@ -77,8 +77,9 @@ SPECULATIVE_POINTS_SMALL = int(os.environ.get("NEGF_SPECULATIVE_SMALL", "512")) 
 def _speculation_budget(F, S=None, g=None):
     """How many new nodes an adaptive integration may evaluate ahead of its convergence test, for this system: zero
     (level by level, the reference's own sequence) unless the levels really are fused into one pass of the engine
-    (integrate.can_fuse_segments: a device-lowerable ``g``, no energy sharding, no spin-block split) -- otherwise every
-    speculated level would cost a launch of its own, up to 486 nodes where the reference stops after 18."""
+    (integrate.can_fuse_segments: a device-lowerable ``g``; per rank and with one all-reduce under energy sharding, per
+    block for a spin-block system) -- otherwise every speculated level would cost a launch of its own, up to 486 nodes
+    where the reference stops after 18."""
     if SPECULATIVE_POINTS <= 0:
         return 0
     if g is not None and not _integrate.can_fuse_segments(F, S, g):
@@ -404,19 +405,42 @@ def densityGrid(F, S, g, mu1, mu2, ind=None, tol=ADAPTIVE_INTEGRATION_TOL, T=TEM
 
 
 def densityComplexN(F, S, g, Emin, mu, N=100, T=TEMPERATURE, showText=True, method='ant'):
-    """Equilibrium density from the complex contour (density.py:660-748)."""
+    """Equilibrium density from the complex contour (density.py:660-748).  At T > 0 the contour and the Fermi-broadening
+    segment go to the engine as ONE pass (GrIntSegments) and are added in the reference's order."""
     Elist, weights = contour_grid(Emin, mu, N, T, method)
     if showText:
         print(f'Complex Integration over {N} points...')
-    lineInt = GrInt(F, S, g, Elist, weights)
-    if T > 0:
+    if T > 0 and GrInt is _ENGINE_GRINT:
         if showText:
             print('Integrating Fermi Broadening')
-        Eb, wb = broadening_grid(mu, N, T, method)
-        lineInt += GrInt(F, S, g, Eb, wb)
+        lineInt, tail = GrIntSegments(F, S, g, [(Elist, weights), broadening_grid(mu, N, T, method)])
+        lineInt = lineInt + tail
+    else:
+        lineInt = GrInt(F, S, g, Elist, weights)
+        if T > 0:
+            if showText:
+                print('Integrating Fermi Broadening')
+            Eb, wb = broadening_grid(mu, N, T, method)
+            lineInt += GrInt(F, S, g, Eb, wb)
     if showText:
         print('Integration done!')
     return (1 + 0j) * np.imag(lineInt) / np.pi
+
+
+def densityEquilibriumN(F, S, g, Eminf, Emin, mu, N_real=100, N_contour=100, T=TEMPERATURE, method='ant'):
+    """(densityRealN(F, S, g, Eminf, Emin, N_real, T=0), densityComplexN(F, S, g, Emin, mu, N_contour, T)) -- the two
+    fixed-grid integrals of a density step at a given Fermi level (scfE.py:316-328, :444-446) -- from ONE pass of the
+    engine over the real-axis grid below Emin, the contour and its Fermi-broadening segment (GrIntSegments; sharded over
+    the ranks of a multi-GPU run as one grid with one all-reduce)."""
+    if GrInt is not _ENGINE_GRINT:
+        return (densityRealN(F, S, g, Eminf, Emin, N_real, T=0, showText=False),
+                densityComplexN(F, S, g, Emin, mu, N_contour, T, showText=False, method=method))
+    segs = [real_axis_grid(Eminf, Emin, N_real, 0), contour_grid(Emin, mu, N_contour, T, method)]
+    if T > 0:
+        segs.append(broadening_grid(mu, N_contour, T, method))
+    sums = GrIntSegments(F, S, g, segs)
+    lineInt = sums[1] + sums[2] if T > 0 else sums[1]
+    return (-1 + 0j) * np.imag(sums[0]) / (np.pi), (1 + 0j) * np.imag(lineInt) / np.pi
 
 
 def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATURE, debug=False):

@@ -204,6 +204,50 @@ def sharded_device_sum(engine, run_dev, E, w):
     return torch.view_as_complex(host).numpy().copy()
 
 
+def sharded_device_seg_sums(engine, run_dev, segs):
+    """Several integrals of one system as ONE pass and ONE collective: ``segs`` = [(E, w), ...] (complex128, the same on
+    every rank).  The points of all segments together are dealt out cyclically -- point t of the concatenated grid goes to
+    rank t mod W, so a level of two nodes and a contour of 486 balance as one grid --, ``run_dev(m, E_ptr, w_ptr, ends,
+    out_ptr)`` launches the engine's ``*_seg_dev`` entry point on the rank's share (``ends``: index one past each segment
+    within the share), the [nseg, n, n] partial sums stay in HBM and are all-reduced in place, then downloaded once.
+    Returns the list of full sums."""
+    import torch
+    dist = _dist()
+    rank, world = rank_world()
+    dev = torch.device("cuda", engine.device)
+    Es, ws, ends, index, off = [], [], [], [], 0
+    for E, w in segs:
+        E = np.asarray(E).ravel(); w = np.asarray(w).ravel()
+        mine = np.arange((rank - off) % world, E.size, world)
+        Es.append(E[mine]); ws.append(w[mine]); index.append(off + mine)
+        ends.append((ends[-1] if ends else 0) + mine.size)
+        off += E.size
+    m = int(ends[-1]) if ends else 0
+
+    def to_dev(a):
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        return torch.view_as_complex(torch.from_numpy(a.view(np.float64).reshape(-1, 2).copy())).to(dev)
+    out = torch.zeros((len(segs), engine.n, engine.n), dtype=torch.complex128, device=dev)
+    if m:
+        E_t, w_t = to_dev(np.concatenate(Es)), to_dev(np.concatenate(ws))
+        torch.cuda.current_stream(dev).synchronize()    # (zero fill and uploads: torch's stream; the engine has its own)
+        run_dev(m, E_t.data_ptr(), w_t.data_ptr(), np.asarray(ends, dtype=np.int32), out.data_ptr())
+    engine.sync()
+    if m:
+        engine.warn_if_singular_dev(m, "sharded integrals", grid_index=np.concatenate(index))
+    flat = torch.view_as_real(out)
+    if dist.get_backend(_state["group"]) == "nccl":
+        with _timed_collective(flat):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_state["group"])
+        host = out.cpu().numpy()
+    else:
+        h = flat.cpu()
+        with _timed_collective(h):
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=_state["group"])
+        host = torch.view_as_complex(h).numpy().copy()
+    return [host[k] for k in range(len(segs))]
+
+
 def sharded_sum(partial_fn, m):
     """``partial_fn(idx)`` returns the partial sum over energy indices ``idx``;
     returns the full sum on every rank."""

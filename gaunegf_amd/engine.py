@@ -374,6 +374,19 @@ class Engine:
         check(self._lib.negf_gless_int_dev(self._ctx, handle, _ind(ind), int(m), C.c_void_p(E_ptr),
                                            C.c_void_p(w_ptr), C.c_void_p(out_ptr)), "negf_gless_int_dev")
 
+    def gr_int_seg_dev(self, handle, m, E_ptr, w_ptr, ends, out_ptr):
+        """negf_gr_int_seg_dev: ``ends`` (host, int32) = index one past each segment; out [len(ends)][n][n] on the device."""
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        self.counters["calls"] += 1; self.counters["points"] += int(m)
+        check(self._lib.negf_gr_int_seg_dev(self._ctx, handle, int(m), C.c_void_p(E_ptr), C.c_void_p(w_ptr), int(ends.size),
+                                            _ptr(ends), C.c_void_p(out_ptr)), "negf_gr_int_seg_dev")
+
+    def gless_int_seg_dev(self, handle, ind, m, E_ptr, w_ptr, ends, out_ptr):
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        self.counters["calls"] += 1; self.counters["points"] += int(m)
+        check(self._lib.negf_gless_int_seg_dev(self._ctx, handle, _ind(ind), int(m), C.c_void_p(E_ptr), C.c_void_p(w_ptr),
+                                               int(ends.size), _ptr(ends), C.c_void_p(out_ptr)), "negf_gless_int_seg_dev")
+
     def transmission_dev(self, handle, contact_L, contact_R, m, E_ptr, T_ptr, Tspin_ptr=0, spin_block=False):
         self.counters["calls"] += 1; self.counters["points"] += int(m)
         mode = NEGF_SPIN_BLOCK if spin_block else NEGF_SPIN_RESTRICTED

@@ -220,45 +220,97 @@ def GrInt(F, S, g, Elist, weights):
 
 
 def can_fuse_segments(F, S, g):
-    """True when GrIntSegments / GrLessIntSegments evaluate several integrals of this system in ONE pass of the engine:
-    ``g`` lowers to a device-side provider, the energy grid is not sharded across ranks and the system is not split
-    into spin blocks.  Everything else falls back to one GrInt per segment -- callers that evaluate levels AHEAD of a
-    convergence test (density._speculation_budget) must not speculate then: every speculated level would be a launch
-    (and, sharded, an all-reduce) of its own."""
-    return hasattr(g, "_negf_lower") and not _dist.is_active() and not _split_depth and \
-        _spin_split(np.asarray(F), np.asarray(S), g) is None
+    """True when GrIntSegments / GrLessIntSegments evaluate several integrals of this system in ONE pass of the engine
+    (per spin block, and per rank when the energy grid is sharded -- then with ONE all-reduce for all of them): ``g``
+    lowers to a device-side provider, directly or block by block.  Everything else (foreign providers evaluated on the
+    host) falls back to one GrInt per segment -- callers that evaluate levels AHEAD of a convergence test
+    (density._speculation_budget) must not speculate then: every speculated level would be a launch of its own."""
+    if hasattr(g, "_negf_lower") and not hasattr(g, "_negf_spin_split"):
+        return True
+    if _split_depth:
+        return hasattr(g, "_negf_lower")
+    parts = _spin_split(np.asarray(F), np.asarray(S), g)
+    if parts is None:
+        return hasattr(g, "_negf_lower")
+    return all(hasattr(gb, "_negf_lower") for _, _, _, gb in parts)
+
+
+def _blockwise_segments(F, S, g, nseg, call):
+    """The spin blocks of a block-diagonal system, each through ``call(F_block, S_block, g_block) -> [nseg sums]``."""
+    global _split_depth
+    if _split_depth:
+        return None
+    parts = _spin_split(F, S, g)
+    if parts is None:
+        return None
+    outs = [np.zeros(F.shape, dtype=np.complex128) for _ in range(nseg)]
+    _split_depth += 1
+    try:
+        for sl, Fb, Sb, gb in parts:
+            for o, v in zip(outs, call(Fb, Sb, gb)):
+                o[sl, sl] = v
+    except _NotBlockDiagonal:
+        return None
+    finally:
+        _split_depth -= 1
+    return outs
+
+
+def _c128_segments(segs):
+    return [(np.ascontiguousarray(E.ravel(), dtype=np.complex128), np.ascontiguousarray(w.ravel(), dtype=np.complex128))
+            for E, w in segs]
 
 
 def GrIntSegments(F, S, g, segments):
     """``[GrInt(F, S, g, E, w) for (E, w) in segments]`` from ONE pass of the engine over all the energies
-    (negf_gr_int_seg) when ``g`` lives on the device; a plain loop of GrInt otherwise (foreign providers, spin-block
-    splitting, energy sharding across ranks).  The adaptive integrations of density.py hand the levels they are about
-    to visit over together: a level of 2 ... 36 points alone in a launch is latency, not work."""
+    (negf_gr_int_seg; under energy sharding negf_gr_int_seg_dev on the rank's share of all the segments and ONE
+    all-reduce of the stacked sums; a block-diagonal spin system block by block) when ``g`` lives on the device; a
+    plain loop of GrInt otherwise (foreign providers).  The adaptive integrations of density.py hand the levels they
+    are about to visit over together -- a level of 2 ... 36 points alone in a launch is latency, not work -- and a density
+    step its contour and real-axis grids (scfE.py:316-328)."""
     F = np.asarray(F)
     S = np.asarray(S)
     segs = [(np.asarray(E), np.asarray(w)) for E, w in segments]
     for E, w in segs:
         _check(F, S, E, w)
-    if not hasattr(g, "_negf_lower") or _dist.is_active() or _split_depth or _spin_split(F, S, g) is not None or len(segs) < 2:
+    if len(segs) < 2:
+        return [GrInt(F, S, g, E, w) for E, w in segs]
+    split = _blockwise_segments(F, S, g, len(segs), lambda Fb, Sb, gb: GrIntSegments(Fb, Sb, gb, segs))
+    if split is not None:
+        return split
+    if not hasattr(g, "_negf_lower"):
         return [GrInt(F, S, g, E, w) for E, w in segs]
     engine = get_engine()
     engine.set_system(F, S)
-    return engine.gr_int_seg(g._negf_lower(engine), segs)
+    h = g._negf_lower(engine)
+    if _dist.is_active():
+        return _dist.sharded_device_seg_sums(
+            engine, lambda m, Ep, wp, ends, op: engine.gr_int_seg_dev(h, m, Ep, wp, ends, op), _c128_segments(segs))
+    return engine.gr_int_seg(h, segs)
 
 
 def GrLessIntSegments(F, S, g, segments, ind=None):
-    """``[GrLessInt(F, S, g, E, w, ind) for (E, w) in segments]`` from one pass of the engine (negf_gless_int_seg); a plain
-    loop under the same conditions as GrIntSegments."""
+    """``[GrLessInt(F, S, g, E, w, ind) for (E, w) in segments]`` from one pass of the engine (negf_gless_int_seg /
+    negf_gless_int_seg_dev); a plain loop under the same conditions as GrIntSegments."""
     F = np.asarray(F)
     S = np.asarray(S)
     segs = [(np.asarray(E), np.asarray(w)) for E, w in segments]
     for E, w in segs:
         _check(F, S, E, w)
-    if not hasattr(g, "_negf_lower") or _dist.is_active() or _split_depth or _spin_split(F, S, g) is not None or len(segs) < 2:
+    if len(segs) < 2:
+        return [GrLessInt(F, S, g, E, w, ind) for E, w in segs]
+    split = _blockwise_segments(F, S, g, len(segs), lambda Fb, Sb, gb: GrLessIntSegments(Fb, Sb, gb, segs, ind))
+    if split is not None:
+        return split
+    if not hasattr(g, "_negf_lower"):
         return [GrLessInt(F, S, g, E, w, ind) for E, w in segs]
     engine = get_engine()
     engine.set_system(F, S)
-    return engine.gless_int_seg(g._negf_lower(engine), ind, segs)
+    h = g._negf_lower(engine)
+    if _dist.is_active():
+        return _dist.sharded_device_seg_sums(
+            engine, lambda m, Ep, wp, ends, op: engine.gless_int_seg_dev(h, ind, m, Ep, wp, ends, op), _c128_segments(segs))
+    return engine.gless_int_seg(h, ind, segs)
 
 
 def GrLessInt(F, S, g, Elist, weights, ind=None):

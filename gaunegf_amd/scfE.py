@@ -27,7 +27,7 @@ from .config import (ADAPTIVE_INTEGRATION_TOL, ENERGY_MIN, FERMI_CALCULATION_TOL
                      SCF_CONVERGENCE_TOL, SCF_MAX_CYCLES, PULAY_MIXING_SIZE)
 from .density import (bisectFermi, density, calcEmin, calcFermiBisect, calcFermiMuller, calcFermiPolyFit, calcFermiSecant,
                       densityComplex, densityComplexN, densityGrid, densityGridN, densityReal,
-                      densityRealN, integralFit, integralFitNEGF)
+                      densityEquilibriumN, densityRealN, integralFit, integralFitNEGF)
 
 har_to_eV = 27.211386   # eV/Hartree (scfE.py:44)
 
@@ -124,7 +124,12 @@ class NEGFE:
         """Density matrix for the current Fock matrix (scfE.py:301-462).  Returns the sorted
         orbital energies and their occupations; ``self.P`` holds the density matrix."""
         F, S, g = self.F, self.S, self.g
-        if self.N2 is None:                                                 # scfE.py:316-320
+        # fixed grids at a given Fermi level: the real-axis integral and the contour are independent -- one pass of the
+        # engine over both grids (density.densityEquilibriumN), the same two sums added in the same order
+        P2_fixed = None
+        if self.N2 is not None and self.N1 is not None and not self.updFermi:
+            P, P2_fixed = densityEquilibriumN(F, S, g, self.Eminf, self.Emin, self.mu1, self.N2, self.N1, self.T)
+        elif self.N2 is None:                                               # scfE.py:316-320
             self.Emin = calcEmin(F, S, g)
             P = densityReal(F, S, g, self.Eminf, self.Emin, self.tol, T=0)
         else:
@@ -199,7 +204,7 @@ class NEGFE:
             self.Emin += self.fermi - fermi_old
             self.g.setF(F, self.mu1, self.mu2)
         else:
-            P = P + compContourP2(self.mu1)                                 # scfE.py:444-446
+            P = P + (P2_fixed if P2_fixed is not None else compContourP2(self.mu1))     # scfE.py:444-446
 
         if self.mu1 != self.mu2:                                            # scfE.py:449-457
             if self.Nnegf is not None:

@@ -194,6 +194,13 @@ int negf_gr_int_dev(negf_ctx* ctx, int handle, int m, const double* E_dev,
                     const double* w_dev, double* out_dev);
 int negf_gless_int_dev(negf_ctx* ctx, int handle, int ind, int m, const double* E_dev,
                        const double* w_dev, double* out_dev);
+/* negf_gr_int_seg / negf_gless_int_seg with grid, weights and the nseg results [nseg][n][n] in HBM (seg_end stays a host
+ * array): several integrals of one system -- contour + real axis of a density step (scfE.py:316-328), the levels of an
+ * adaptive integration -- as ONE pass over this rank's shard of all their energies and ONE all-reduce of out_dev. */
+int negf_gr_int_seg_dev(negf_ctx* ctx, int handle, int m, const double* E_dev, const double* w_dev,
+                        int nseg, const int* seg_end, double* out_dev);
+int negf_gless_int_seg_dev(negf_ctx* ctx, int handle, int ind, int m, const double* E_dev, const double* w_dev,
+                           int nseg, const int* seg_end, double* out_dev);
 int negf_transmission_dev(negf_ctx* ctx, int handle, int contact_L, int contact_R,
                           int spin_mode, int m, const double* E_dev,
                           double* T_dev, double* Tspin_dev);

@@ -51,6 +51,23 @@ import pstats
 p = pstats.Stats("gpurun_out/r5_${c}_share8.prof"); p.sort_stats("cumulative").print_stats(45)
 PY
        done > gpurun_out/r5_hostprof.log 2>&1; grep -E "ms_per_step" gpurun_out/r5_c4_share8_prof.json | cut -c1-200; tail -130 gpurun_out/r5_hostprof.log ;;
+    seg_tests) timeout -k 10 900 python -m pytest tests/test_small_fused_gpu.py tests/test_distributed_gpu.py -x -q -m gpu > gpurun_out/r5_seg_tests.log 2>&1; rc=$?; tail -5 gpurun_out/r5_seg_tests.log; [ $rc -eq 0 ] || exit $rc ;;
+    scf_small) timeout -k 10 600 python bench.py --config scf --scf-systems ${SCF_SYSTEMS:-n60,n200} --no-cpu --steps 5 > gpurun_out/r5_scf_small.json 2> gpurun_out/r5_scf_small.err || exit 1
+       python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5_scf_small.json"))
+for s in d["config"]["systems"]:
+    print(s["system"], "wall %.2f ms  kernels %.2f ms  calls %.0f  points %.0f" % (s["wall_ms_per_step"], s["kernel_ms_per_step"], s["integrals_per_step"], s["energy_points_per_step"]), {k: round(v, 2) for k, v in s["family_ms_per_step"].items()})
+PY
+       ;;
+    scf_kstats) rm -rf gpurun_out/r5_scfks; cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r5_scfks -o ks -- python3 $GRAFT_REPO_ROOT/scripts/prof_scf_host.py ${SCF_SYSTEMS:-n60} 5 > $GRAFT_REPO_ROOT/gpurun_out/r5_scfks.log 2>&1; rc=$?; cd $GRAFT_REPO_ROOT; [ $rc -eq 0 ] || { tail -20 gpurun_out/r5_scfks.log; exit $rc; }
+       f=$(find gpurun_out/r5_scfks -name "*kernel_stats.csv" | head -1); python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:12]:
+    print(f"{r['Name'][:100]:100s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} avg_us {float(r['AverageNs'])/1e3:9.1f} {r['Percentage']}%")
+PY
+       find gpurun_out/r5_scfks -name "*.db" -delete; find gpurun_out/r5_scfks -name "*trace.csv" -delete ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done

@@ -216,8 +216,9 @@ def test_calc_emin_reference_route_is_bit_identical(monkeypatch):
 
 def test_speculation_only_where_levels_are_fused():
     """density._speculation_budget: levels are evaluated ahead of the convergence test only when GrIntSegments really
-    fuses them into one pass (a device-lowerable provider, no energy sharding, no spin-block split); a foreign provider
-    gets the reference's level-by-level sequence (budget 0) -- speculated levels would cost a launch each."""
+    fuses them into one pass (a device-lowerable provider -- also per rank of an energy-sharded run, where the fused levels
+    share ONE all-reduce, and per spin block); a foreign provider gets the reference's level-by-level sequence
+    (budget 0) -- speculated levels would cost a launch each."""
     F = np.eye(60); S = np.eye(60)
 
     class Foreign:
@@ -231,13 +232,18 @@ def test_speculation_only_where_levels_are_fused():
     assert D._speculation_budget(F, S, Foreign()) == 0
     assert D._speculation_budget(F, S, Lowerable()) == D.SPECULATIVE_POINTS_SMALL
     from gaunegf_amd import distributed as dist
-    was = dist._state.get("active") if hasattr(dist, "_state") else None
-    try:
-        import unittest.mock as um
-        with um.patch.object(dist, "is_active", lambda: True):
-            assert D._speculation_budget(F, S, Lowerable()) == 0
-    finally:
-        del was
+    import unittest.mock as um
+    with um.patch.object(dist, "is_active", lambda: True):
+        assert D._speculation_budget(F, S, Lowerable()) == D.SPECULATIVE_POINTS_SMALL
+        assert D._speculation_budget(F, S, Foreign()) == 0
+    # a block-diagonal spin system: fused when the provider serves its blocks on the device (surfGTest does)
+    from gaunegf_amd.surfGTester import surfGTest
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((20, 20)); A = A + A.T
+    F2 = np.kron(np.eye(2), A); S2 = np.eye(40)
+    g = surfGTest(F2, S2, [[0, 20], [19, 39]], -0.1j)
+    assert D._speculation_budget(F2, S2, g) == D.SPECULATIVE_POINTS_SMALL
+    assert D._speculation_budget(F2, S2, Foreign()) == 0
 
 
 def test_engine_keeps_conversions_of_unchanged_system_matrices():

@@ -294,6 +294,85 @@ def test_segments_across_workspace_chunks(engine):
         assert rel_fro(a, b) < 1e-12
 
 
+def test_segments_on_the_windowed_inverse_and_on_spin_blocks(engine):
+    """negf_gr_int_seg above the single-workgroup sizes: every segment's sum reads the windowed inverse through its pivot
+    bookkeeping (no gather), segments straddling workspace chunks included; an exactly singular energy poisons its own
+    segment only.  A block-diagonal spin system goes block by block, every block's segments in one pass."""
+    import warnings
+    from gaunegf_amd.integrate import GrInt, GrIntSegments, GrLessInt, GrLessIntSegments
+    from gaunegf_amd.surfGTester import surfGTest
+    F, S, g, g_ref = _const(300, 41)
+    rng = np.random.default_rng(9)
+    segs = [(rng.uniform(-2, 2, k) + 0.05j, rng.standard_normal(k) + 0j) for k in (3, 1, 20, 9)]
+    ref = [GrInt(F, S, g, E, w) for E, w in segs]
+    for batch in (0, 7):
+        engine.set_batch(batch)
+        try:
+            got = GrIntSegments(F, S, g, segs)
+        finally:
+            engine.set_batch(0)
+        for a, b in zip(got, ref):
+            assert rel_fro(a, b) < 1e-12
+    assert rel_fro(got[2], oracle.GrInt(F, S, g_ref, *segs[2])) < TOL
+    # E S - F - Sigma exactly singular at one energy of segment 1 (F = S, Sigma = 0 staged per energy: E = 1 gives the zero matrix)
+    engine.set_system(S, S)
+    Es = [np.array([0.5 + 0.1j, 2.0 + 0.1j]), np.array([1.0 + 0j, 3.0 + 0.2j])]
+    h = engine.sigma_precomputed(np.zeros((4, 300, 300), dtype=complex))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            out = engine.gr_int_seg(h, [(e, np.ones(2) + 0j) for e in Es])
+    finally:
+        engine.sigma_free(h)
+    Si = np.linalg.inv(S)
+    assert rel_fro(out[0], Si / (0.5 + 0.1j - 1) + Si / (2.0 + 0.1j - 1)) < TOL and np.all(np.isnan(out[1].real))
+    assert list(np.nonzero(engine.last_info)[0]) == [2]
+    # spin blocks
+    N = 130
+    Fa, Sa = random_system(N, 3); Fb, _ = random_system(N, 4)
+    F2 = np.block([[Fa, np.zeros((N, N))], [np.zeros((N, N)), Fb]]); S2 = np.kron(np.eye(2), Sa)
+    inds = [[0, 1, 2, N, N + 1, N + 2], [N - 3, N - 2, N - 1, 2 * N - 3, 2 * N - 2, 2 * N - 1]]
+    g2 = surfGTest(F2, S2, inds, -0.1j)
+    segs2 = [(rng.uniform(-1, 1, k) + 0.02j, rng.standard_normal(k) + 0j) for k in (2, 11)]
+    for a, (E, w) in zip(GrIntSegments(F2, S2, g2, segs2), segs2):
+        b = GrInt(F2, S2, g2, E, w)
+        assert rel_fro(a, b) < 1e-12 and not np.any(a[:N, N:]) and not np.any(a[N:, :N])
+    for a, (E, w) in zip(GrLessIntSegments(F2, S2, g2, segs2, -1), segs2):
+        assert rel_fro(a, GrLessInt(F2, S2, g2, E, w, -1)) < 1e-12
+
+
+def test_fixed_grid_density_step_in_one_pass(engine):
+    """density.densityEquilibriumN = (densityRealN, densityComplexN) from one pass over the three grids; NEGFE.FockToP with
+    fixed grids at a given Fermi level uses it and reproduces the oracle-served step."""
+    import contextlib, io
+    from gaunegf_amd import density as D
+    from gaunegf_amd.scfE import NEGFE
+    F, S, g, g_ref = _const(60, 5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        calls0 = engine.counters["calls"]
+        Pr, Pc = D.densityEquilibriumN(F, S, g, -50.0, -3.0, 0.1, 24, 40, 300.0)
+        assert engine.counters["calls"] - calls0 == 1
+        assert rel_fro(Pr, D.densityRealN(F, S, g, -50.0, -3.0, 24, T=0, showText=False)) < 1e-12
+        assert rel_fro(Pc, D.densityComplexN(F, S, g, -3.0, 0.1, 40, 300.0, showText=False)) < 1e-12
+
+        def step(gobj):
+            n = NEGFE(F, S, gobj, ne=24, spin='r', T=300.0, Eminf=-50.0)
+            n.setIntegralLimits(N1=40, N2=24, Emin=-3.0)
+            n.setVoltage(0.0, fermi=0.1)
+            n.FockToP()
+            return n.P
+        calls0 = engine.counters["calls"]
+        P = step(g)
+        assert engine.counters["calls"] - calls0 == 1
+        saved = (D.GrInt, D.GrLessInt)
+        D.GrInt, D.GrLessInt = oracle.GrInt, oracle.GrLessInt
+        try:
+            P_ref = step(g_ref)
+        finally:
+            D.GrInt, D.GrLessInt = saved
+    assert rel_fro(P, P_ref) < TOL
+
+
 @pytest.mark.parametrize("N", [24, 60, 130])
 def test_segmented_lesser_integrals_and_adaptive_bias_window(engine, N, capsys):
     """negf_gless_int_seg: every segment's G Gamma G^H sum equals GrLessInt on that segment alone (ind = None, 0, -1;
