@@ -262,6 +262,46 @@ __global__ __launch_bounds__(SF_THREADS) void small_fused_kernel(SmallFusedArgs 
     }
 }
 
+// pivot search of the columns-per-wave layouts, by the wave that holds column k (lane = row, RPL rows per lane).
+// |re| + |im| >= 0 orders like its bit pattern: wave maximum of the high words, then of the low words among the lanes that
+// hold it; the lowest row wins (LAPACK's izamax rule).  An exactly singular or NaN column takes the lowest unused row and
+// reports k + 1.  The result is wave-uniform.
+template <int RPL>
+__device__ __forceinline__ int cw_pivot_search(const cplx (&col)[RPL], const bool (&used)[RPL], int lane, int n, int k, int* bad_s)
+{
+    unsigned h_[RPL], l_[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const double v = cabs1(col[r]);
+        const bool ok = lane + 64 * r < n && !used[r] && v > 0.0;
+        h_[r] = ok ? (unsigned)__double2hiint(v) : 0u;
+        l_[r] = ok ? (unsigned)__double2loint(v) : 0u;
+    }
+    unsigned hmax = h_[0];
+    if (RPL == 2) hmax = h_[RPL - 1] > hmax ? h_[RPL - 1] : hmax;
+    const unsigned hm = sf_wave_max_u32(hmax);
+    unsigned lcand = h_[0] == hm ? l_[0] : 0u;
+    if (RPL == 2) { const unsigned l1 = h_[RPL - 1] == hm ? l_[RPL - 1] : 0u; lcand = l1 > lcand ? l1 : lcand; }
+    const unsigned lm = sf_wave_max_u32(lcand);
+    int p;
+    if (hm != 0u || lm != 0u) {
+        const unsigned long long b0 = __ballot(h_[0] == hm && l_[0] == lm);
+        const unsigned long long b1 = RPL == 2 ? __ballot(h_[RPL - 1] == hm && l_[RPL - 1] == lm) : 0ull;
+        p = b0 ? (int)__ffsll((long long)b0) - 1 : 64 + (int)__ffsll((long long)b1) - 1;
+    } else {
+        const unsigned long long f0 = __ballot(lane < n && !used[0]);
+        const unsigned long long f1 = RPL == 2 ? __ballot(lane + 64 < n && !used[RPL - 1]) : 0ull;
+        p = f0 ? (int)__ffsll((long long)f0) - 1 : 64 + (int)__ffsll((long long)f1) - 1;
+        if (lane == 0) atomicCAS(bad_s, 0, k + 1);
+    }
+    return p;
+}
+
+__device__ __forceinline__ double sf_readlane_f64(double v, int lane)       // (lane: wave-uniform)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
 // ---- second layout (round 4, later; the default): COLUMNS PER WAVE, ROWS PER LANE.  Wave w owns the columns
 // [w CPW, (w+1) CPW), lane l the rows l and l + 64 (RPL = 1 for n <= 64): the tile W[RPL][CPW] is again in registers
 // with static indices, because the pivot steps run as  for (owner wave) for (c = 0 .. CPW-1, unrolled)  -- step
@@ -276,61 +316,170 @@ __global__ __launch_bounds__(SF_THREADS) void small_fused_kernel(SmallFusedArgs 
 //     RPL x CPW complex FMAs on the RAW pivot row: ~150 vector instructions per step and wave against ~350.
 // The matrix is assembled into LDS with coalesced reads first (same operation order as the tile layout), the
 // un-permuted inverse goes back to LDS, and the accumulate / store phases are those of the tile layout.
-template <int RPL, int CPW>
-__global__ __launch_bounds__(SF_THREADS) void small_cw_kernel(SmallFusedArgs a)
+template <int RPL, int CPW, bool PANEL>
+__global__ __launch_bounds__(SF_THREADS, RPL == 1 ? 4 : 2) void small_cw_kernel(SmallFusedArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
-    cplx* Gs = reinterpret_cast<cplx*>(sf_smem);                  // [n][gp]: the assembled matrix, later the un-permuted inverse
-    __shared__ cplx colb[2][128];                                 // pivot column, double buffered by step parity
+    extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];   // PANEL: the panels' multipliers [NBUF][CPW][64 RPL]
+    __shared__ cplx colb[PANEL ? 1 : 2][PANEL ? 1 : 128];         // (!PANEL) pivot column, double buffered by step parity
     __shared__ cplx rowl[4][CPW];                                 // per wave: the pivot row in the wave's columns
-    __shared__ int piv_s[2];                                      // pivot row of the step, by parity
+    __shared__ int piv_s[2];                                      // (!PANEL) pivot row of the step, by parity
     __shared__ int bad_s;
-    __shared__ int pivrow_s[SF_MAXN], colof_s[SF_MAXN];
+    __shared__ int pivrow_s[SF_MAXN + 8], colof_s[SF_MAXN + 8];
 
-    const int n = a.n, gp = a.gp;
+    const int n = a.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int T16 = (n + 15) >> 4;
     const int col0 = wave * CPW;
     cplx* part = a.Gout ? nullptr : a.partial + (size_t)blockIdx.x * n * n;
     bool first = true;
 
     for (int e = blockIdx.x; e < a.m; e += gridDim.x) {
-        // ---- assemble: (E S - H) - Sigma in the reference's order (integrate.py:70), contact blocks one contact after
-        // the other, as scatter_sub_kernel subtracts them; coalesced (thread (ty, tx) walks 16 x 16 patches)
+        // ---- assemble straight into the register tile: (E S - H) - Sigma in the reference's order (integrate.py:70),
+        // contact blocks one contact after the other, as scatter_sub_kernel subtracts them.  Lane = row reads its
+        // CPW consecutive columns (256 contiguous bytes per lane at CPW = 16; S and H are the same for every energy
+        // and stay in L2) -- no LDS copy of the matrix: the kernel's LDS is 6 KB and the register file, not a
+        // 59-KB buffer per workgroup, decides how many matrices a CU works on (n = 60: 2 -> 4)
         const cplx z = a.E[e];
         if (tid == 0) bad_s = 0;
-        for (int r = 0; r < T16; ++r)
-            for (int c = 0; c < T16; ++c) {
-                const int i = ty + 16 * r, j = tx + 16 * c;
+        cplx W[RPL][CPW];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const int i = lane + 64 * r;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int j = col0 + c;
+                cplx v = cmake(0.0, 0.0);
                 if (i < n && j < n) {
                     const int o = i * n + j;
                     const cplx s_ = a.S[o], h = a.H[o];
-                    cplx v = cmake(z.x * s_.x - z.y * s_.y - h.x, z.x * s_.y + z.y * s_.x - h.y);
+                    v = cmake(z.x * s_.x - z.y * s_.y - h.x, z.x * s_.y + z.y * s_.x - h.y);
                     if (a.sig_dense) v = csub(v, a.sig_dense[(size_t)e * a.sig_stride + o]);
                     for (int ct = 0; ct < a.n_contacts; ++ct) {
                         const int pi = a.pos[ct * n + i], pj = a.pos[ct * n + j];
                         if (pi >= 0 && pj >= 0)
                             v = csub(v, a.blk[(size_t)e * a.blk_stride + a.blk_off[ct] + pi * a.nc[ct] + pj]);
                     }
-                    Gs[i * gp + j] = v;
                 }
+                W[r][c] = v;
+                if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (four columns' loads in flight, not all CPW: registers)
             }
-        __syncthreads();
-        cplx W[RPL][CPW];
-#pragma unroll
-        for (int r = 0; r < RPL; ++r)
-#pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-                const int i = lane + 64 * r, j = col0 + c;
-                W[r][c] = (i < n && j < n) ? Gs[i * gp + j] : cmake(0.0, 0.0);
-            }
+        }
         bool used[RPL];                                           // this lane's rows that have been pivots
 #pragma unroll
         for (int r = 0; r < RPL; ++r) used[r] = false;
-        __syncthreads();                                          // Gs is free again (it receives the result below)
+        __syncthreads();                                          // bad_s is reset; the tables of the last matrix are free
 
-        // ---- Gauss-Jordan, implicit partial pivoting, one barrier per step
+        // ---- Gauss-Jordan, implicit partial pivoting.  PANEL (NEGF_SMALL_KERNEL=panel): a wave factors its CPW columns ALONE --
+        // the pivot column lies in its registers (lane = row: DPP maximum), the pivot comes from lane p by v_readlane,
+        // the pivot row in its own columns through the wave-local line -- and publishes the multipliers f (not the raw
+        // column) and the pivot rows of the whole panel; ONE workgroup barrier per panel; then the other three waves run
+        // the panel's CPW steps on their own columns back to back (multipliers and pivot indices prefetched a step ahead,
+        // no barrier, no 1 / pivot).  The next owner applies and goes straight on factoring: that is the look-ahead.
+        // Every element sees the same operations in the same order as in the per-step form below: bitwise equal.
+        if constexpr (PANEL) {
+            constexpr int ROWS = 64 * RPL;
+            constexpr int NBUF = RPL == 1 ? 2 : 1;                // (two rows per lane: one buffer and a second barrier -- LDS)
+            cplx* Fp = reinterpret_cast<cplx*>(sf_smem);
+            for (int q = 0; q < 4; ++q) {
+                if (q * CPW >= n) break;
+                cplx* Fq = Fp + (size_t)(NBUF == 2 ? (q & 1) : 0) * CPW * ROWS;
+                if (wave == q) {
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) {
+                        const int k = q * CPW + c;
+                        if (k < n) {
+                            cplx colv[RPL];
+#pragma unroll
+                            for (int r = 0; r < RPL; ++r) colv[r] = W[r][c];
+                            const int p = __builtin_amdgcn_readfirstlane(cw_pivot_search<RPL>(colv, used, lane, n, k, &bad_s));
+                            const int pl = p & 63, pr = p >> 6;
+                            cplx pv = cmake(sf_readlane_f64(W[0][c].x, pl), sf_readlane_f64(W[0][c].y, pl));
+                            if (RPL == 2 && pr) pv = cmake(sf_readlane_f64(W[RPL - 1][c].x, pl), sf_readlane_f64(W[RPL - 1][c].y, pl));
+                            const double pd = pv.x * pv.x + pv.y * pv.y;
+                            double sc = __builtin_amdgcn_rcp(pd);
+                            sc = fma(sc, fma(-pd, sc, 1.0), sc);
+                            sc = fma(sc, fma(-pd, sc, 1.0), sc);
+                            const cplx ip = cmake(pv.x * sc, -pv.y * sc);
+                            cplx f[RPL];
+#pragma unroll
+                            for (int r = 0; r < RPL; ++r) {
+                                const int i = lane + 64 * r;
+                                const cplx m_ = cmul(W[r][c], ip);
+                                const bool isp = i == p;
+                                f[r] = cmake(isp ? 1.0 - ip.x : m_.x, isp ? -ip.y : m_.y);
+                                used[r] = used[r] || isp;
+                                Fq[c * ROWS + i] = f[r];
+                            }
+                            if (lane == 0) { pivrow_s[k] = p; colof_s[p] = k; }
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane == pl) {                     // (column k becomes e_p: its entry in row p is 1)
+                                if (RPL == 2 && pr) {             // (a uniform branch, not a select between the register rows)
+#pragma unroll
+                                    for (int cc = 0; cc < CPW; ++cc) rowl[wave][cc] = cc == c ? cmake(1.0, 0.0) : W[RPL - 1][cc];
+                                } else {
+#pragma unroll
+                                    for (int cc = 0; cc < CPW; ++cc) rowl[wave][cc] = cc == c ? cmake(1.0, 0.0) : W[0][cc];
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                            for (int r = 0; r < RPL; ++r) W[r][c] = cmake(lane + 64 * r == p ? 1.0 : 0.0, 0.0);
+#pragma unroll
+                            for (int cc = 0; cc < CPW; ++cc) {
+                                const cplx rb = rowl[wave][cc];
+#pragma unroll
+                                for (int r = 0; r < RPL; ++r) W[r][cc] = cfnma(W[r][cc], f[r], rb);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (wave != q) {
+                    cplx fn[RPL];
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r) fn[r] = Fq[lane + 64 * r];
+                    int pn = pivrow_s[q * CPW];
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c) {
+                        const int k = q * CPW + c;
+                        if (k < n) {
+                            const int p = __builtin_amdgcn_readfirstlane(pn);
+                            const int pl = p & 63, pr = p >> 6;
+                            cplx f[RPL];
+#pragma unroll
+                            for (int r = 0; r < RPL; ++r) { f[r] = fn[r]; used[r] = used[r] || lane + 64 * r == p; }
+                            if (c + 1 < CPW) {                    // (the next step's multipliers and pivot row: in flight over this step)
+#pragma unroll
+                                for (int r = 0; r < RPL; ++r) fn[r] = Fq[(c + 1) * ROWS + lane + 64 * r];
+                                pn = pivrow_s[k + 1];
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane == pl) {
+                                if (RPL == 2 && pr) {
+#pragma unroll
+                                    for (int cc = 0; cc < CPW; ++cc) rowl[wave][cc] = W[RPL - 1][cc];
+                                } else {
+#pragma unroll
+                                    for (int cc = 0; cc < CPW; ++cc) rowl[wave][cc] = W[0][cc];
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                            for (int cc = 0; cc < CPW; ++cc) {
+                                const cplx rb = rowl[wave][cc];
+#pragma unroll
+                                for (int r = 0; r < RPL; ++r) W[r][cc] = cfnma(W[r][cc], f[r], rb);
+                            }
+                        }
+                    }
+                }
+                if (NBUF == 1) __syncthreads();                   // the single buffer is rewritten by the next owner
+            }
+        } else
+        // ---- the per-step form (the default): the owner publishes column and pivot row, one barrier per step
         for (int ow = 0; ow < 4; ++ow) {
             if (ow * CPW >= n) break;
 #pragma unroll
@@ -339,33 +488,10 @@ __global__ __launch_bounds__(SF_THREADS) void small_cw_kernel(SmallFusedArgs a)
                 if (k < n) {                                      // (uniform; the steps beyond n fall away at the tail)
                     const int buf = k & 1;
                     if (wave == ow) {
-                        // owner: pivot search on its own registers.  |re| + |im| >= 0 orders like its bit pattern: wave
-                        // maximum of the high words, then of the low words among the lanes that hold it; lowest row wins
-                        unsigned h_[RPL], l_[RPL];
+                        cplx colv[RPL];
 #pragma unroll
-                        for (int r = 0; r < RPL; ++r) {
-                            const double v = cabs1(W[r][c]);
-                            const bool ok = lane + 64 * r < n && !used[r] && v > 0.0;
-                            h_[r] = ok ? (unsigned)__double2hiint(v) : 0u;
-                            l_[r] = ok ? (unsigned)__double2loint(v) : 0u;
-                        }
-                        unsigned hmax = h_[0];
-                        if (RPL == 2) hmax = h_[RPL - 1] > hmax ? h_[RPL - 1] : hmax;
-                        const unsigned hm = sf_wave_max_u32(hmax);
-                        unsigned lcand = h_[0] == hm ? l_[0] : 0u;
-                        if (RPL == 2) { const unsigned l1 = h_[RPL - 1] == hm ? l_[RPL - 1] : 0u; lcand = l1 > lcand ? l1 : lcand; }
-                        const unsigned lm = sf_wave_max_u32(lcand);
-                        int p;
-                        if (hm != 0u || lm != 0u) {
-                            const unsigned long long b0 = __ballot(h_[0] == hm && l_[0] == lm);
-                            const unsigned long long b1 = RPL == 2 ? __ballot(h_[RPL - 1] == hm && l_[RPL - 1] == lm) : 0ull;
-                            p = b0 ? (int)__ffsll((long long)b0) - 1 : 64 + (int)__ffsll((long long)b1) - 1;
-                        } else {                                  // exactly singular or NaN column: lowest unused row
-                            const unsigned long long f0 = __ballot(lane < n && !used[0]);
-                            const unsigned long long f1 = RPL == 2 ? __ballot(lane + 64 < n && !used[RPL - 1]) : 0ull;
-                            p = f0 ? (int)__ffsll((long long)f0) - 1 : 64 + (int)__ffsll((long long)f1) - 1;
-                            if (lane == 0) atomicCAS(&bad_s, 0, k + 1);
-                        }
+                        for (int r = 0; r < RPL; ++r) colv[r] = W[r][c];
+                        const int p = cw_pivot_search<RPL>(colv, used, lane, n, k, &bad_s);
 #pragma unroll
                         for (int r = 0; r < RPL; ++r) colb[buf][lane + 64 * r] = W[r][c];
                         if (lane == 0) { piv_s[buf] = p; pivrow_s[k] = p; colof_s[p] = k; }
@@ -416,44 +542,34 @@ __global__ __launch_bounds__(SF_THREADS) void small_cw_kernel(SmallFusedArgs a)
                 }
             }
         }
-        // ---- un-permute through LDS: W[r][c] is G[colof[r]][pivrow[c]]  (pivrow / colof / bad_s are complete: every
-        // step's owner wrote them in front of that step's barrier)
+        // ---- W[r][c] is G[colof[r]][pivrow[c]] (pivrow / colof / bad_s are complete: every step's owner wrote them in
+        // front of that step's barrier): the weighted sum (or G itself) goes straight to its place in memory -- lane =
+        // one row of G, its CPW entries at permuted columns; the four waves fill the row between them
         const int bad = bad_s;
         const double qnan = __builtin_nan("");
+        if (tid == 0 && a.info) a.info[e] = bad;
+        cplx* out = a.Gout ? a.Gout + (size_t)e * a.g_stride : part;
+        const cplx w = a.Gout ? cmake(0.0, 0.0) : a.w[e];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             const int i = lane + 64 * r;
             if (i < n) {
-                const int gi = colof_s[i];
+                cplx* orow = out + (size_t)colof_s[i] * n;
 #pragma unroll
                 for (int c = 0; c < CPW; ++c) {
                     const int j = col0 + c;
-                    if (j < n) Gs[gi * gp + pivrow_s[j]] = bad ? cmake(qnan, qnan) : W[r][c];
+                    if (j < n) {
+                        const cplx g = bad ? cmake(qnan, qnan) : W[r][c];
+                        const int gj = pivrow_s[j];
+                        if (a.Gout) orow[gj] = g;
+                        else orow[gj] = cfma(first ? cmake(0.0, 0.0) : orow[gj], w, g);   // acc += w G, as accumulate_partial_kernel
+                    }
+                    if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        if (tid == 0 && a.info) a.info[e] = bad;
-        __syncthreads();
-        if (a.Gout) {
-            cplx* out = a.Gout + (size_t)e * a.g_stride;
-            for (int r = 0; r < T16; ++r)
-                for (int c = 0; c < T16; ++c) {
-                    const int i = ty + 16 * r, j = tx + 16 * c;
-                    if (i < n && j < n) out[i * n + j] = Gs[i * gp + j];
-                }
-        } else {
-            const cplx w = a.w[e];
-            for (int r = 0; r < T16; ++r)
-                for (int c = 0; c < T16; ++c) {
-                    const int i = ty + 16 * r, j = tx + 16 * c;
-                    if (i < n && j < n) {
-                        const cplx old = first ? cmake(0.0, 0.0) : part[i * n + j];
-                        part[i * n + j] = cfma(old, w, Gs[i * gp + j]);      // acc += w G, as accumulate_partial_kernel
-                    }
-                }
-            first = false;
-        }
-        __syncthreads();                                          // Gs, the pivot tables and the buffers are reused
+        first = false;
+        __syncthreads();                                          // the pivot tables and the buffers are reused
     }
 }
 
@@ -510,15 +626,11 @@ __global__ __launch_bounds__(256) void small_reduce_seg_kernel(int n2, SegEnds s
 }
 
 template <int RPL, int CPW>
-void cw_launch(hipStream_t st, const SmallFusedArgs& a, int grid, size_t smem)
+void cw_launch(hipStream_t st, const SmallFusedArgs& a, int grid, bool panel)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_cw_kernel<RPL, CPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                150 * 1024) != hipSuccess) (void)hipGetLastError();
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((small_cw_kernel<RPL, CPW>), dim3(grid), dim3(SF_THREADS), smem, st, a);
+    constexpr size_t panel_lds = (size_t)(RPL == 1 ? 2 : 1) * CPW * 64 * RPL * sizeof(cplx);     // <= 48 KB
+    if (panel) hipLaunchKernelGGL((small_cw_kernel<RPL, CPW, true>), dim3(grid), dim3(SF_THREADS), panel_lds, st, a);
+    else hipLaunchKernelGGL((small_cw_kernel<RPL, CPW, false>), dim3(grid), dim3(SF_THREADS), 0, st, a);
 }
 
 template <int T>
@@ -537,31 +649,48 @@ void sf_launch(hipStream_t st, const SmallFusedArgs& a, int grid, size_t smem)
 
 bool small_fused_supported(int n) { return n >= 1 && n <= SF_MAXN; }
 
+// NEGF_SMALL_KERNEL (A/B, cross-checks): "tile" = the 16 x 16 thread-grid layout (1), "panel" = columns per wave with one
+// barrier per PANEL of CPW pivot steps (0); default "cw": columns per wave, one barrier per pivot step (2).  The panel form
+// is bitwise equal and measured SLOWER (MI355X, kernel time per call: one n = 60 matrix 100 against 85 us, 972 points
+// 210 against 201 us; n = 96: 283 / 222 and 747 / 631 us): the other three waves of a workgroup idle while one factors,
+// and the per-step chain search -> 1 / pivot -> pivot row -> update is as long inside one wave as across the barrier.
+static int sf_layout()
+{
+    static int layout = -1;
+    if (layout < 0) { const char* e = getenv("NEGF_SMALL_KERNEL"); layout = !e ? 2 : strcmp(e, "tile") == 0 ? 1 : strcmp(e, "panel") == 0 ? 0 : 2; }
+    return layout;
+}
+
 int small_fused_grid(int n, int m)
 {
-    // resident workgroups: the LDS holds one un-permuted inverse per workgroup
-    const size_t smem = (size_t)n * (n | 1) * sizeof(cplx) + 8 * 1024;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / smem));
+    // resident workgroups per CU.  Columns-per-wave layouts: no matrix in LDS (the panel form: 8 ... 48 KB of multipliers),
+    // the register tile decides (n <= 64: 128 VGPRs, four waves per SIMD; above: 256, two).  Tile layout: the LDS holds
+    // one un-permuted inverse per workgroup.
+    int per_cu;
+    if (sf_layout() != 1) per_cu = n <= 64 ? 4 : 2;
+    else {
+        const size_t smem = (size_t)n * (n | 1) * sizeof(cplx) + 8 * 1024;
+        per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / smem));
+    }
     return std::max(1, std::min(m, 256 * per_cu));
 }
 
 void launch_small_fused(hipStream_t st, SmallFusedArgs a)
 {
     if (a.m <= 0) return;
-    a.gp = a.n | 1;                                               // odd pitch
+    a.gp = a.n | 1;                                               // odd pitch (tile layout)
     const size_t smem = (size_t)a.n * a.gp * sizeof(cplx);
     // segments (a.nseg > 0): one workgroup and one partial record per energy, summed per segment below
     const int grid = a.nseg > 0 ? a.m : small_fused_grid(a.n, a.m);
     const int T = (a.n + 15) / 16;
-    static int layout = -1;                       // NEGF_SMALL_KERNEL=tile: the 16 x 16 thread-grid layout (A/B, cross-check)
-    if (layout < 0) { const char* e = getenv("NEGF_SMALL_KERNEL"); layout = (e && strcmp(e, "tile") == 0) ? 1 : 0; }
-    if (layout == 0) switch (T) {
-    case 1: cw_launch<1, 4>(st, a, grid, smem); break;
-    case 2: cw_launch<1, 8>(st, a, grid, smem); break;
-    case 3: cw_launch<1, 12>(st, a, grid, smem); break;
-    case 4: cw_launch<1, 16>(st, a, grid, smem); break;
-    case 5: cw_launch<2, 20>(st, a, grid, smem); break;
-    default: cw_launch<2, 24>(st, a, grid, smem); break;
+    const int layout = sf_layout();
+    if (layout != 1) switch (T) {
+    case 1: cw_launch<1, 4>(st, a, grid, layout == 0); break;
+    case 2: cw_launch<1, 8>(st, a, grid, layout == 0); break;
+    case 3: cw_launch<1, 12>(st, a, grid, layout == 0); break;
+    case 4: cw_launch<1, 16>(st, a, grid, layout == 0); break;
+    case 5: cw_launch<2, 20>(st, a, grid, layout == 0); break;
+    default: cw_launch<2, 24>(st, a, grid, layout == 0); break;
     }
     else switch (T) {
     case 1: sf_launch<1>(st, a, grid, smem); break;

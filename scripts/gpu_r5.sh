@@ -68,6 +68,10 @@ for r in rows[:12]:
     print(f"{r['Name'][:100]:100s} calls {r['Calls']:>6s} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} avg_us {float(r['AverageNs'])/1e3:9.1f} {r['Percentage']}%")
 PY
        find gpurun_out/r5_scfks -name "*.db" -delete; find gpurun_out/r5_scfks -name "*trace.csv" -delete ;;
+    small_tests) timeout -k 10 900 python -m pytest tests/test_small_fused_gpu.py -x -q -m gpu > gpurun_out/r5_small_tests.log 2>&1; rc=$?; tail -3 gpurun_out/r5_small_tests.log; [ $rc -eq 0 ] || exit $rc
+       timeout -k 10 600 python scripts/fuzz_small.py > gpurun_out/r5_fuzz_small.log 2>&1; rc=$?; tail -3 gpurun_out/r5_fuzz_small.log; [ $rc -eq 0 ] || exit $rc ;;
+    small_calls) timeout -k 10 600 python scripts/time_small_calls.py ${SMALL_N:-60 96} > gpurun_out/r5_small_calls.log 2>&1 || exit 1; grep -E "GrInt " gpurun_out/r5_small_calls.log; grep Segments gpurun_out/r5_small_calls.log ;;
+    small_ab) for k in cw panel; do echo "NEGF_SMALL_KERNEL=$k"; NEGF_SMALL_KERNEL=$k timeout -k 10 300 python scripts/time_small_calls.py ${SMALL_N:-60 96} 2>&1 | grep -E "GrInt +m= +(2|324)|972"; done | tee gpurun_out/r5_small_ab.log ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done

@@ -33,3 +33,12 @@ for N in [int(a) for a in sys.argv[1:]] or [60, 200]:
     for _ in range(60):
         t = time.perf_counter(); GrIntSegments(F, S, g, segs); ts.append(time.perf_counter() - t)
     print(f"n={N} GrIntSegments 2+4+12+36: median {np.median(ts)*1e6:7.1f} us  min {np.min(ts)*1e6:7.1f} us", flush=True)
+    segs = [(rng.uniform(-2, 2, k) + 0.1j, np.ones(k)) for k in (2, 4, 12, 36, 108, 324) * 2]      # a joint arc + tail probe, all levels
+    for _ in range(5):
+        GrIntSegments(F, S, g, segs)
+    ts = []
+    for _ in range(60):
+        t = time.perf_counter(); GrIntSegments(F, S, g, segs); ts.append(time.perf_counter() - t)
+    eng.profile(True); eng.profile_reset(); GrIntSegments(F, S, g, segs)
+    kern = sum(eng.profile_read(k)[0] for k in bench.SCF_FAMILIES); eng.profile(False)
+    print(f"n={N} GrIntSegments 972 points in 12 segments: median {np.median(ts)*1e6:7.1f} us  min {np.min(ts)*1e6:7.1f} us   kernel {kern*1e3:7.1f} us", flush=True)

@@ -277,6 +277,37 @@ def test_tile_layout_kernel_in_a_fresh_process():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_panel_form_equals_the_per_step_form_bitwise(engine, tmp_path):
+    """NEGF_SMALL_KERNEL=panel factors a wave's columns as one panel (one workgroup barrier per panel; measured slower, kept
+    as a cross-check); the default is the same layout with one barrier per pivot step.  Both apply the same operations to every
+    element in the same order: G(E) and the weighted sums must agree BITWISE, for every tile class, off the real axis,
+    with a singular energy in the batch (same info, same NaN fill)."""
+    import os, subprocess, sys, textwrap
+    from gaunegf_amd.integrate import GrBatch, GrInt
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from test_small_fused_gpu import _const
+        from gaunegf_amd.integrate import GrBatch, GrInt
+        out = {}
+        for N in (1, 7, 16, 17, 33, 48, 60, 64, 65, 80, 81, 96):
+            F, S, g, g_ref = _const(N, 40 + N)
+            E = np.concatenate([np.linspace(-2.5, 2.5, 5) + 1e-6j, [0.3 + 0.7j]]); w = np.linspace(0.5, 1.5, E.size) * (1 + 0.2j)
+            out["G%%d" %% N] = GrBatch(F, S, g, E); out["I%%d" %% N] = GrInt(F, S, g, E, w)
+        np.savez(sys.argv[1], **out)
+        print("ok")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    f = str(tmp_path / "panel.npz")
+    r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, NEGF_SMALL_KERNEL="panel"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    ref = np.load(f)
+    for N in (1, 7, 16, 17, 33, 48, 60, 64, 65, 80, 81, 96):
+        F, S, g, g_ref = _const(N, 40 + N)
+        E = np.concatenate([np.linspace(-2.5, 2.5, 5) + 1e-6j, [0.3 + 0.7j]]); w = np.linspace(0.5, 1.5, E.size) * (1 + 0.2j)
+        assert np.array_equal(GrBatch(F, S, g, E), ref["G%d" % N]), N
+        assert np.array_equal(GrInt(F, S, g, E, w), ref["I%d" % N]), N
+
+
 def test_segments_across_workspace_chunks(engine):
     """The kernel-sequence path of negf_gr_int_seg streams the energies through the workspace in chunks: segments that
     straddle chunk boundaries (a workspace of 5 energies, segments of 2, 4, 12 and 7 points) still sum correctly."""
