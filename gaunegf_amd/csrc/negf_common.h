@@ -173,7 +173,7 @@ struct negf_ctx {
     // the last NEGF_SYS_SLOTS systems handed to negf_set_system stay on the device (with a host copy to recognise
     // them by): front-ends that alternate between two systems -- the two spin blocks of a blockdiag(alpha, beta)
     // Fock matrix, scf.py:177-180 -- re-select instead of re-uploading
-    struct SysSlot { cplx* dF = nullptr; cplx* dS = nullptr; std::vector<cplx> hF, hS; unsigned long long used = 0; bool valid = false; };
+    struct SysSlot { cplx* dF = nullptr; cplx* dS = nullptr; std::vector<cplx> hF, hS; unsigned long long used = 0, key = 0; bool valid = false; };
     static constexpr int NEGF_SYS_SLOTS = 2;
     SysSlot sys[NEGF_SYS_SLOTS];
     int sys_cur = -1;

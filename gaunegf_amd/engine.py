@@ -132,37 +132,51 @@ class Engine:
     def set_system(self, F, S):
         """Make F, S the resident system.  The library keeps the last two systems on the device and recognises them
         bitwise (negf_set_system): calls that repeat a system, or alternate between two -- the spin blocks of a
-        blockdiag(alpha, beta) Fock matrix -- upload nothing."""
-        F = self._c128_cached(F)
-        S = self._c128_cached(S)
+        blockdiag(alpha, beta) Fock matrix -- upload nothing.  Matrices that reach the library as this engine's own
+        private complex copies (``_c128_keyed``) carry a key and are recognised without the comparison."""
+        F, kF = self._c128_keyed(F)
+        S, kS = self._c128_keyed(S)
         assert F.shape == S.shape, "F and S must have the same shape"
         assert F.ndim == 2 and F.shape[0] == F.shape[1], "F and S must be square matrices"
         n_changed = F.shape[0] != self.n
-        check(self._lib.negf_set_system(self._ctx, F.shape[0], _ptr(F), _ptr(S)), "negf_set_system")
+        key = (kF << 32) | kS if kF and kS else 0
+        check(self._lib.negf_set_system_keyed(self._ctx, F.shape[0], _ptr(F), _ptr(S), C.c_ulonglong(key)), "negf_set_system")
         self.n = F.shape[0]
         if n_changed:
             self.generation = getattr(self, "generation", 0) + 1   # provider handles died
         return True
 
     def _c128_cached(self, a):
-        """complex128 C-contiguous form of a system matrix.  An SCF step hands the same REAL F and S to every one of its
-        ~30 integrals; converting 2 x 5 MB to complex at N = 800 each time is 2 ms per call.  The conversions of the last
-        four matrices are kept together with a snapshot of their source: the same array object with the same content
-        (compared element by element -- a caller may have changed it in place) gets its conversion back."""
+        return self._c128_keyed(a)[0]
+
+    def _c128_keyed(self, a):
+        """(complex128 C-contiguous form of a system matrix, its serial number or 0).  An SCF step hands the same REAL F and
+        S to every one of its ~30 integrals; converting 2 x 5 MB to complex at N = 800 each time is 2 ms per call.  The
+        conversions of the last four matrices are kept together with a snapshot of their source: the same array object
+        with the same content (compared element by element -- a caller may have changed it in place; an owned read-only
+        array cannot change and is not compared) gets its conversion back.  A kept conversion is private to the engine and
+        never changes: it carries a serial number (never reused) by which the library recognises a resident system
+        without comparing bytes (negf_set_system_keyed).  Arrays handed in as complex128 already are passed through
+        (serial 0: the library compares) unless they are frozen."""
         a = np.asarray(a)
-        if a.dtype == np.complex128 and a.flags.c_contiguous:
-            return a                                              # (nothing to convert)
-        cache = self.__dict__.setdefault("_sys_conv", [])
         frozen = (not a.flags.writeable) and a.base is None       # an owned read-only array (integrate._split_blocks): cannot change
-        for k, (src, snap, conv) in enumerate(cache):
+        ready = a.dtype == np.complex128 and a.flags.c_contiguous
+        if ready and not frozen:
+            return a, 0                                           # (nothing to convert, nothing known about its future)
+        cache = self.__dict__.setdefault("_sys_conv", [])
+        for k, (src, snap, conv, serial) in enumerate(cache):
             if src is a and (snap is None or (snap.shape == a.shape and snap.dtype == a.dtype and np.array_equal(a, snap))):
                 cache.append(cache.pop(k))
-                return conv
-        conv = _c128(a)
+                return conv, serial
+        conv = a if ready else _c128(a)
         if 128 * 128 <= a.size and a.nbytes <= (64 << 20):        # (small: the conversion costs less than the comparison; large: not worth the host memory)
-            cache.append((a, None if frozen else a.copy(), conv))
+            serial = self.__dict__["_sys_serial"] = self.__dict__.get("_sys_serial", 0) + 1
+            if serial >= (1 << 32):
+                return conv, 0
+            cache.append((a, None if frozen else a.copy(), conv, serial))
             del cache[:-4]
-        return conv
+            return conv, serial
+        return conv, 0
 
     # ------------------------------------------------------------ providers
     def sigma_const(self, sigmas):

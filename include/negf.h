@@ -73,6 +73,12 @@ int         negf_get_batch(negf_ctx* ctx);
  * Both n*n complex128 (a real F is passed with zero imaginary parts). */
 int negf_set_system(negf_ctx* ctx, int n, const double* F_c128, const double* S_c128);
 
+/* The same with a caller's key (0: none).  Equal nonzero keys VOUCH that (F, S) are bitwise the matrices handed over with
+ * that key before: a resident system with the key is selected without comparing 2 x 16 n^2 bytes on the host (a front end
+ * that keeps private, immutable complex copies of the caller's matrices numbers them -- gaunegf_amd/engine.py; an entry
+ * point of a per-GPU share of BASELINE C5 spent 4 ms of its 30 comparing).  An unknown key falls back to the comparison. */
+int negf_set_system_keyed(negf_ctx* ctx, int n, const double* F_c128, const double* S_c128, unsigned long long key);
+
 /* ------------------------------------------------- self-energy providers
  * A provider is the device-side lowering of the reference's duck-typed ``g``
  * object (.sigma(E,i) / .sigmaTot(E)).  Handles are small

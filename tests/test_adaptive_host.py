@@ -266,3 +266,15 @@ def test_engine_keeps_conversions_of_unchanged_system_matrices():
     for k in range(6):                                   # the cache holds four matrices
         eng._c128_cached(rng.standard_normal((130, 130)))
     assert len(eng._sys_conv) == 4
+    # serial numbers (negf_set_system_keyed): one per kept conversion, the same while the content is, never reused;
+    # none for arrays the engine holds no private copy of
+    _, k1 = eng._c128_keyed(A)
+    assert k1 > 0 and eng._c128_keyed(A)[1] == k1
+    A[0, 0] -= 2.0
+    _, k2 = eng._c128_keyed(A)
+    assert k2 > k1
+    assert eng._c128_keyed(Z)[1] == 0                    # the caller's own complex array: may change behind our back
+    Zf = Z.copy(); Zf.setflags(write=False)
+    zc, kz = eng._c128_keyed(Zf)
+    assert zc is Zf and kz > k2 and eng._c128_keyed(Zf)[1] == kz      # frozen: passed through, numbered
+    assert eng._c128_keyed(rng.standard_normal((8, 8)))[1] == 0      # small: not kept

@@ -310,6 +310,35 @@ def test_explicit_gammas_need_not_be_hermitian(engine):
         assert abs(got - ref) <= 1e-9 * max(1.0, abs(ref)), (herm, got, ref)
 
 
+def test_keyed_resident_systems(engine):
+    """Systems of >= 128 x 128 reach the library as the engine's private complex copies and carry a key
+    (negf_set_system_keyed): a repeated or alternating system is selected without the bytewise comparison, a third
+    system evicts the least recently used one, a matrix changed IN PLACE gets a new copy and a new key, and frozen
+    (read-only, owned) arrays are numbered without being copied.  Every call must give the result of its own (F, S)."""
+    from gaunegf_amd.integrate import GrInt
+    from gaunegf_amd.surfGTester import surfGTest
+    N = 160
+    systems = [random_system(N, 80 + k) for k in range(3)]
+    E = np.linspace(-1.0, 1.0, 7) + 0.05j
+    w = np.full(7, 0.25) + 0.0j
+    inds = [list(range(5)), list(range(N - 5, N))]
+
+    def check(F, S):
+        g = surfGTest(F, S, inds, -0.1j)
+        ref = oracle.GrInt(np.asarray(F), np.asarray(S), oracle.ConstSigma(np.asarray(F), np.asarray(S), inds, -0.1j), E, w)
+        assert rel_fro(GrInt(F, S, g, E, w), ref) < TOL
+    for k in (0, 1, 0, 1, 2, 0, 1, 2, 2):
+        check(*systems[k])
+    F, S = systems[1]
+    F[3, 3] += 0.25; F[7, 2] -= 0.1; F[2, 7] -= 0.1        # changed in place: a different system under the same array object
+    check(F, S)
+    check(*systems[2]); check(F, S)
+    Ff = F.astype(np.complex128); Sf = S.astype(np.complex128)
+    Ff.setflags(write=False); Sf.setflags(write=False)
+    check(Ff, Sf); check(*systems[0]); check(Ff, Sf)
+    assert engine._c128_keyed(Ff)[1] > 0 and engine._c128_keyed(Ff)[0] is Ff
+
+
 def test_resident_systems_are_recognised_bitwise(engine):
     """negf_set_system keeps the last two systems on the device and re-selects one it recognises bit for bit: alternating
     between two systems (the spin blocks of a blockdiag Fock matrix), a third one evicting the least recently used, and a
