@@ -38,6 +38,7 @@ SIGNATURES = {
     "negf_get_batch": (C.c_int, [_vp]),
     "negf_set_system": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "negf_set_system_keyed": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_ulonglong]),
+    "negf_hash_bytes": (C.c_ulonglong, [_vp, C.c_ulonglong]),
     "negf_sigma_const": (C.c_int, [_vp, C.c_int, _vp, _ip]),
     "negf_sigma_chain1d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _ip]),

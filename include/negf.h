@@ -73,6 +73,10 @@ int         negf_get_batch(negf_ctx* ctx);
  * Both n*n complex128 (a real F is passed with zero imaginary parts). */
 int negf_set_system(negf_ctx* ctx, int n, const double* F_c128, const double* S_c128);
 
+/* 64-bit checksum of a host buffer (no context, no GPU; large buffers on up to 8 threads): what the front end's caches use
+ * to notice that a caller changed a matrix in place between two entry points (gaunegf_amd/engine.py fingerprint). */
+unsigned long long negf_hash_bytes(const void* data, unsigned long long bytes);
+
 /* The same with a caller's key (0: none).  Equal nonzero keys VOUCH that (F, S) are bitwise the matrices handed over with
  * that key before: a resident system with the key is selected without comparing 2 x 16 n^2 bytes on the host (a front end
  * that keeps private, immutable complex copies of the caller's matrices numbers them -- gaunegf_amd/engine.py; an entry
