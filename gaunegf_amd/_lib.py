@@ -52,6 +52,7 @@ SIGNATURES = {
     "negf_gr_int": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "negf_gr_int_seg": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "negf_gless_int_seg": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "negf_gr_int_refine": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "negf_gless_int": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "negf_gr_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "negf_transmission": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

@@ -346,6 +346,75 @@ void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx
     hipLaunchKernelGGL(accumulate_final_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nchunks, part, acc);
 }
 
+// ------------------------------------------------------------------ nested refinement (density.py:239-268)
+// One workgroup per integral.  sums [levels][n2]: the weighted sums over the NEW nodes of consecutive levels of the nested rule;
+// the reference's update and stopping test, level by level and in its operation order:
+//     first level of an integration (ratio = NaN):  P = sum                                        (no test)
+//     every other level:  new_P = P * ratio;  new_P += sum;  maxDP = max |new_P - P|;  P = new_P;  stop when maxDP < tol
+// (P * ratio is numpy's complex128 x (ratio + 0j) product; |.| = hypot).  P [n2] holds the running value on entry (levels with a
+// ratio) and the value of the last level consumed on exit; level_out = index of the level that converged, -1 if none did;
+// maxdp_out [levels] the maxDP of every level consumed (NaN where there is none).  A NaN anywhere makes maxDP NaN (numpy's max),
+// which never converges -- as in the reference.
+__global__ __launch_bounds__(1024) void refine_levels_kernel(int n2, const cplx* __restrict__ sums, const int* __restrict__ first,
+                                                             const double* __restrict__ ratio, double tol, cplx* __restrict__ P,
+                                                             int* __restrict__ level_out, double* __restrict__ maxdp_out)
+{
+    __shared__ double red[16];
+    __shared__ int red_nan[16];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int s0 = first[k], s1 = first[k + 1];
+    cplx* Pk = P + (size_t)k * n2;
+    const double qnan = __builtin_nan("");
+    int conv = -1;
+    for (int s = s0; s < s1; ++s) {
+        const cplx* inc = sums + (size_t)s * n2;
+        const double r = ratio[s];
+        if (r != r) {                                             // first level of the integration
+            for (int i = tid; i < n2; i += 1024) Pk[i] = inc[i];
+            if (tid == 0) maxdp_out[s] = qnan;
+            __syncthreads();
+            continue;
+        }
+        double mx = 0.0;
+        int any_nan = 0;
+        for (int i = tid; i < n2; i += 1024) {
+            const cplx p = Pk[i];
+            // (p.x + i p.y)(r + i 0), every term as numpy forms it
+            cplx q = cmake(p.x * r - p.y * 0.0, p.x * 0.0 + p.y * r);
+            const cplx v = inc[i];
+            q = cmake(q.x + v.x, q.y + v.y);
+            const double a = hypot(q.x - p.x, q.y - p.y);
+            if (a != a) any_nan = 1; else mx = a > mx ? a : mx;
+            Pk[i] = q;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(mx, off, 64);
+            mx = o > mx ? o : mx;
+            any_nan |= __shfl_down(any_nan, off, 64);
+        }
+        if ((tid & 63) == 0) { red[tid >> 6] = mx; red_nan[tid >> 6] = any_nan; }
+        __syncthreads();
+        double m_all = red[0];
+        int n_all = red_nan[0];
+        for (int q = 1; q < 16; ++q) { m_all = red[q] > m_all ? red[q] : m_all; n_all |= red_nan[q]; }
+        const double maxdp = n_all ? qnan : m_all;
+        if (tid == 0) maxdp_out[s] = maxdp;
+        __syncthreads();                                          // red is reused by the next level
+        if (maxdp < tol) { conv = s - s0; break; }                // (uniform)
+    }
+    if (tid == 0) {
+        level_out[k] = conv;
+        for (int s = s0 + (conv < 0 ? s1 - s0 : conv + 1); s < s1; ++s) maxdp_out[s] = qnan;   // levels not consumed
+    }
+}
+
+void launch_refine_levels(hipStream_t st, int n2, int nint, const cplx* sums, const int* first, const double* ratio, double tol,
+                          cplx* P, int* level_out, double* maxdp_out)
+{
+    hipLaunchKernelGGL(refine_levels_kernel, dim3(nint), dim3(1024), 0, st, n2, sums, first, ratio, tol, P, level_out, maxdp_out);
+}
+
 // ------------------------------------------------------------------ reductions
 __device__ __forceinline__ double wave_sum(double v)
 {

@@ -782,7 +782,7 @@ void negf_destroy(negf_ctx* c)
     }
     for (auto& sl : c->sys) { dev_free(sl.dF); dev_free(sl.dS); }
     c->d_F = c->d_S = nullptr;
-    dev_free(c->d_acc); dev_free(c->d_seg_out);
+    dev_free(c->d_acc); dev_free(c->d_seg_out); dev_free(c->d_ref_P); dev_free(c->d_ref_meta);
     prof_resolve(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
@@ -1674,6 +1674,91 @@ int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const doubl
     if (m > 0) NEGF_HIP_CHECK(hipMemcpyAsync(pinfo, c->d_info, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if ((rc = wait_stream(c))) return rc;
     copy_bytes(out, pout, nseg * n2 * sizeof(cplx));
+    rc = NEGF_OK;
+    for (int i = 0; i < m; ++i) { if (info) info[i] = pinfo[i]; if (pinfo[i] != 0) rc = NEGF_ESINGULAR; }
+    return rc;
+}
+
+// Adaptive nested quadrature with the refinement ON THE DEVICE (integratePointsAdaptiveANT, density.py:211-273): the m energies
+// are the NEW nodes of consecutive levels of nint integrations (nlev[k] levels each, seg_end as in negf_gr_int_seg over all
+// sum(nlev) levels, integral after integral); ratio[s] is the nested-weight ratio of level s -- NaN for the first level of an
+// integration, which then starts from that level's sum; otherwise the integration continues from P_in[k].  One pass evaluates
+// every level's sum, refine_levels_kernel runs the reference's update and stopping test level by level, and only the result comes
+// back: P_out [nint][n][n] (the value at the converged level, or after the last level), level_out [nint] (index of the
+// converged level within the call, -1: not converged, continue with P_out as P_in), maxdp_out [sum(nlev)].  Saves the host the
+// level sums (12 x n^2 per Fermi probe), the five numpy passes per level over them, and their download.  n <= REF_MAX_N.
+int negf_gr_int_refine(negf_ctx* c, int handle, int m, const double* E, const double* w, int nint, const int* nlev,
+                       const int* seg_end, const double* ratio, double tol, const double* P_in, double* P_out,
+                       int* level_out, double* maxdp_out, int* info)
+{
+    SigmaProvider* p = get_provider(c, handle);
+    int rc = check_ready(c, p, m);
+    if (rc) return rc;
+    if (!P_out || !level_out || !maxdp_out || !nlev || !ratio || nint <= 0 || nint > REF_MAX_INTS || (m > 0 && (!E || !w))) return NEGF_EINVAL;
+    if (c->n > REF_MAX_N) return NEGF_EINVAL;
+    int nseg = 0;
+    std::vector<int> first(nint + 1, 0);
+    for (int k = 0; k < nint; ++k) { if (nlev[k] <= 0) return NEGF_EINVAL; nseg += nlev[k]; first[k + 1] = nseg; }
+    if (nseg > REF_MAX_LEVELS || check_segments(m, nseg, seg_end)) return NEGF_EINVAL;
+    for (int k = 0; k < nint; ++k) {
+        for (int s = first[k] + 1; s < first[k + 1]; ++s) if (ratio[s] != ratio[s]) return NEGF_EINVAL;      // only a first level starts an integration
+        if (ratio[first[k]] == ratio[first[k]] && !P_in) return NEGF_EINVAL;                                  // a continued one needs its running value
+    }
+    NEGF_HIP_CHECK(hipSetDevice(c->device));
+    const size_t n2 = (size_t)c->n * c->n;
+    const size_t gb = (size_t)m * sizeof(cplx), pb = (size_t)nint * n2 * sizeof(cplx);
+    const size_t meta_b = (size_t)REF_MAX_LEVELS * 16 + (size_t)(2 * REF_MAX_INTS + 1) * 4;
+    if ((rc = ensure_pinned(c, 2 * gb + pb + meta_b + (size_t)m * sizeof(int) + 256))) return rc;
+    if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
+    if ((size_t)nseg * n2 > c->seg_out_cap) {
+        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+        dev_free(c->d_seg_out); c->seg_out_cap = 0;
+        if ((rc = dev_alloc(&c->d_seg_out, (size_t)nseg * n2))) return rc;
+        c->seg_out_cap = (size_t)nseg * n2;
+    }
+    if ((size_t)nint * n2 > c->ref_P_cap) {
+        NEGF_HIP_CHECK(hipStreamSynchronize(c->stream));
+        dev_free(c->d_ref_P); c->ref_P_cap = 0;
+        if ((rc = dev_alloc(&c->d_ref_P, (size_t)nint * n2))) return rc;
+        c->ref_P_cap = (size_t)nint * n2;
+    }
+    if (!c->d_ref_meta && (rc = dev_alloc(&c->d_ref_meta, meta_b))) return rc;
+    // pinned layout: [E | w | P (in, then out) | ratio | maxdp | first | level | info]
+    unsigned char* pP = c->h_pin + 2 * gb;
+    unsigned char* pmeta = pP + pb;
+    double* h_ratio = reinterpret_cast<double*>(pmeta);
+    double* h_maxdp = h_ratio + REF_MAX_LEVELS;
+    int* h_first = reinterpret_cast<int*>(h_maxdp + REF_MAX_LEVELS);
+    int* h_level = h_first + REF_MAX_INTS + 1;
+    int* pinfo = h_level + REF_MAX_INTS;
+    double* d_ratio = reinterpret_cast<double*>(c->d_ref_meta);
+    double* d_maxdp = d_ratio + REF_MAX_LEVELS;
+    int* d_first = reinterpret_cast<int*>(d_maxdp + REF_MAX_LEVELS);
+    int* d_level = d_first + REF_MAX_INTS + 1;
+    std::memcpy(h_ratio, ratio, (size_t)nseg * sizeof(double));
+    std::memcpy(h_first, first.data(), (size_t)(nint + 1) * sizeof(int));
+    NEGF_HIP_CHECK(hipMemcpyAsync(d_ratio, h_ratio, (size_t)nseg * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NEGF_HIP_CHECK(hipMemcpyAsync(d_first, h_first, (size_t)(nint + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < nint; ++k)
+        if (ratio[first[k]] == ratio[first[k]]) {                // continued: its running value goes up
+            std::memcpy(pP + (size_t)k * n2 * sizeof(cplx), P_in + (size_t)k * n2 * 2, n2 * sizeof(cplx));
+            NEGF_HIP_CHECK(hipMemcpyAsync(c->d_ref_P + (size_t)k * n2, pP + (size_t)k * n2 * sizeof(cplx), n2 * sizeof(cplx),
+                                          hipMemcpyHostToDevice, c->stream));
+        }
+    if ((rc = gr_seg_core(c, p, m, c->d_E, c->d_w, nseg, seg_end, c->d_seg_out))) return rc;
+    {
+        ProfScope ps(c, "accumulate");
+        launch_refine_levels(c->stream, (int)n2, nint, c->d_seg_out, d_first, d_ratio, tol, c->d_ref_P, d_level, d_maxdp);
+    }
+    NEGF_HIP_CHECK(hipGetLastError());
+    NEGF_HIP_CHECK(hipMemcpyAsync(pP, c->d_ref_P, pb, hipMemcpyDeviceToHost, c->stream));
+    NEGF_HIP_CHECK(hipMemcpyAsync(h_maxdp, d_maxdp, (size_t)nseg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NEGF_HIP_CHECK(hipMemcpyAsync(h_level, d_level, (size_t)nint * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (m > 0) NEGF_HIP_CHECK(hipMemcpyAsync(pinfo, c->d_info, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    copy_bytes(P_out, pP, pb);
+    std::memcpy(maxdp_out, h_maxdp, (size_t)nseg * sizeof(double));
+    std::memcpy(level_out, h_level, (size_t)nint * sizeof(int));
     rc = NEGF_OK;
     for (int i = 0; i < m; ++i) { if (info) info[i] = pinfo[i]; if (pinfo[i] != 0) rc = NEGF_ESINGULAR; }
     return rc;

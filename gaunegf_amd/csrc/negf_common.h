@@ -220,6 +220,9 @@ struct negf_ctx {
     size_t gsmall_cap = 0;
     cplx* d_seg_out = nullptr;     // [segments][n*n] results of negf_gr_int_seg
     size_t seg_out_cap = 0;
+    cplx* d_ref_P = nullptr;       // [integrals][n*n] running values of negf_gr_int_refine
+    size_t ref_P_cap = 0;
+    unsigned char* d_ref_meta = nullptr;   // its level table: ratio[REF_MAX_LEVELS] | maxdp[REF_MAX_LEVELS] | first[REF_MAX_INTS + 1] | level[REF_MAX_INTS]
     cplx* d_small_part = nullptr;  // per-workgroup partial sums of the small fused kernel
     size_t small_part_cap = 0;
     GjSideStreams gj_side;
@@ -282,6 +285,10 @@ void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx
 // the same sum over matrices still in their reduced, un-gathered form: X[b][i][j] = W[b][pivrow_b[i]][colof_b[j]] (piv = [nb][2][n];
 // a matrix with info[b] != 0 counts as NaN, as its gathered form would)
 void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const cplx* W, const int* piv, const int* info, cplx* acc, cplx* part);
+// nested refinement on the device (density.py:239-268): see refine_levels_kernel
+constexpr int REF_MAX_LEVELS = 2048, REF_MAX_INTS = 64, REF_MAX_N = 512;
+void launch_refine_levels(hipStream_t st, int n2, int nint, const cplx* sums, const int* first, const double* ratio, double tol,
+                          cplx* P, int* level_out, double* maxdp_out);
 void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cplx* out);
 size_t accumulate_scratch_elems(int n2, int nb);
 

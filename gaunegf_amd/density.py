@@ -229,6 +229,46 @@ def integrateJointlyAdaptiveANT(node_grids, computeSegments, tol=ADAPTIVE_INTEGR
     return result
 
 
+REFINE_ON_DEVICE = os.environ.get("NEGF_REFINE_ON_DEVICE", "1") != "0"   # adaptive GrInt integrations: update + stopping test in the library
+
+
+def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, budget=None):
+    """integrateJointlyAdaptiveANT with the refinement itself on the device: every round hands the levels each integration
+    is about to visit (up to ``budget`` new nodes, as _adaptive_ant_steps groups them) to ``refine`` -- ONE pass of the
+    engine, which applies the reference's update and stopping test level by level (density.py:239-268) and returns the value
+    at the level that converged, or after the last one together with the fact that it did not.  What the host no longer does:
+    receive a sum per level and run five numpy passes over each.  Messages as in _adaptive_ant_steps."""
+    levels = _ant_levels(maxN)
+    if budget is None:
+        budget = SPECULATIVE_POINTS
+    K = len(node_grids)
+    nxt, running, result = [0] * K, [None] * K, [None] * K
+    active = list(range(K))
+    while active:
+        groups, requests = [], []
+        for k in active:
+            group, pts = [], 0
+            for j in range(nxt[k], len(levels)):
+                if group and pts + levels[j][1].size > budget:
+                    break
+                group.append(j); pts += levels[j][1].size
+            groups.append(group)
+            requests.append(([node_grids[k](levels[j][1], levels[j][2]) + (levels[j][3],) for j in group], running[k]))
+        still = []
+        for k, group, (value, conv, maxdps) in zip(active, groups, refine(requests, tol)):
+            if conv >= 0:
+                print(f'Adaptive integration converged to {maxdps[conv]:.3e} in {levels[group[conv]][0]} points.')
+                result[k] = value
+            elif group[-1] == len(levels) - 1:
+                print(f'Adaptive integration reached full grid ({levels[-1][0] / 1} points), final error {maxdps[-1]:.3e}')
+                result[k] = value
+            else:
+                running[k], nxt[k] = value, group[-1] + 1
+                still.append(k)
+        active = still
+    return result
+
+
 # ------------------------------------------------------------ grid builders
 def real_axis_grid(Emin, mu, N, T):
     """(Elist, weights) of densityRealN (density.py:418-427)."""
@@ -472,16 +512,26 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
                                           if GrInt is _ENGINE_GRINT else None,
                                           budget=_speculation_budget(F, S, g))
 
-    if T > 0 and GrInt is _ENGINE_GRINT and not debug and _speculation_budget(F, S, g) > 0:
-        # the contour and the Fermi tail refine together: one launch per round for both (integrateJointlyAdaptiveANT)
+    fused = GrInt is _ENGINE_GRINT and not debug and _speculation_budget(F, S, g) > 0
+    refine = _integrate.GrIntRefiner(F, S, g) if fused and REFINE_ON_DEVICE else None
+    if T > 0 and fused:
+        # the contour and the Fermi tail refine together: one launch per round for both (integrateJointlyAdaptiveANT; where
+        # the library can run the refinement itself, _refine_jointly: only the refined values come back)
         print('Complex Contour Integration (with the Fermi broadening):')
-        total, tail = integrateJointlyAdaptiveANT([grid_of(on_arc), grid_of(on_tail)],
-                                                  lambda segs: GrIntSegments(F, S, g, segs), tol=tol,
-                                                  budget=_speculation_budget(F, S, g))
-        total += tail
+        if refine is not None:
+            total, tail = _refine_jointly([grid_of(on_arc), grid_of(on_tail)], refine, tol=tol, budget=_speculation_budget(F, S, g))
+            total = total + tail
+        else:
+            total, tail = integrateJointlyAdaptiveANT([grid_of(on_arc), grid_of(on_tail)],
+                                                      lambda segs: GrIntSegments(F, S, g, segs), tol=tol,
+                                                      budget=_speculation_budget(F, S, g))
+            total += tail
         return (1 + 0j) * np.imag(total) / np.pi
     print('Complex Contour Integration:')
-    total = integral_over(on_arc)
+    if refine is not None:
+        total = _refine_jointly([grid_of(on_arc)], refine, tol=tol, budget=_speculation_budget(F, S, g))[0]
+    else:
+        total = integral_over(on_arc)
     if T > 0:
         print('Integrating Fermi Broadening:')
         total += integral_over(on_tail)

@@ -317,6 +317,49 @@ class Engine:
         self._numerical(rc, info[:E.size], "gr_int_seg")
         return [out[k] for k in range(len(segments))]
 
+    REFINE_MAX_N = 512                                            # negf_gr_int_refine: one workgroup walks an integral's levels
+    REFINE_MAX_INTEGRALS, REFINE_MAX_LEVELS = 64, 2048
+
+    def gr_int_refine(self, handle, requests, tol):
+        """Nested adaptive refinement on the device (negf_gr_int_refine).  ``requests`` = [(levels, P_in)] per integral, with
+        ``levels`` = [(E, w, ratio)] the NEW nodes of consecutive levels of the nested rule (``ratio`` None for the first
+        level of an integration) and ``P_in`` the running value of an integration that continues (None otherwise).
+        Returns [(P, converged, maxdps)]: the value at the converged level (``converged`` = its index in ``levels``) or after
+        the last level (``converged`` = -1), and the maxDP of every level consumed (NaN for a first level)."""
+        Es, ws, ends, ratios, nlev = [], [], [], [], []
+        for levels, P_in in requests:
+            nlev.append(len(levels))
+            for j, (E, w, ratio) in enumerate(levels):
+                E = np.asarray(E).ravel(); w = np.asarray(w).ravel()
+                assert E.size == w.size, "Elist and weights must have the same length"
+                assert (ratio is None) == (j == 0 and P_in is None), "only the first level of a fresh integration has no ratio"
+                Es.append(E); ws.append(w); ratios.append(np.nan if ratio is None else float(ratio))
+                ends.append((ends[-1] if ends else 0) + E.size)
+        E, w = self._grid(np.concatenate(Es), np.concatenate(ws))
+        nint = len(requests)
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        nlev = np.ascontiguousarray(nlev, dtype=np.int32)
+        ratios = np.ascontiguousarray(ratios, dtype=np.float64)
+        P_in = None
+        if any(P is not None for _, P in requests):
+            P_in = np.zeros((nint, self.n, self.n), dtype=np.complex128)
+            for k, (_, P) in enumerate(requests):
+                if P is not None:
+                    P_in[k] = P
+        out = np.empty((nint, self.n, self.n), dtype=np.complex128)
+        level = np.zeros(nint, dtype=np.int32)
+        maxdp = np.zeros(ends.size, dtype=np.float64)
+        info = np.zeros(max(E.size, 1), dtype=np.int32)
+        rc = check(self._lib.negf_gr_int_refine(self._ctx, handle, E.size, _ptr(E), _ptr(w), nint, _ptr(nlev), _ptr(ends),
+                                                _ptr(ratios), C.c_double(tol), _ptr(P_in), _ptr(out), _ptr(level), _ptr(maxdp),
+                                                _ptr(info)), "negf_gr_int_refine")
+        self._numerical(rc, info[:E.size], "gr_int_refine")
+        res, s = [], 0
+        for k in range(nint):
+            res.append((out[k], int(level[k]), maxdp[s:s + nlev[k]].copy()))
+            s += int(nlev[k])
+        return res
+
     def gless_int_seg(self, handle, ind, segments):
         """[sum_m w_m G Gamma G^H for (E, w) in segments] from ONE pass over all the energies (negf_gless_int_seg)."""
         Es = [np.asarray(E).ravel() for E, _ in segments]

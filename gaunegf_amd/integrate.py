@@ -289,6 +289,30 @@ def GrIntSegments(F, S, g, segments):
     return engine.gr_int_seg(h, segs)
 
 
+def GrIntRefiner(F, S, g):
+    """``refine(requests, tol)`` -- the nested adaptive refinement of one or several GrInt integrals of this system with the
+    update and the stopping test ON THE DEVICE (Engine.gr_int_refine / negf_gr_int_refine: the level sums never leave HBM,
+    only the refined value comes back) -- or None where that form does not apply: a provider evaluated on the host, an
+    energy-sharded run (the level sums are all-reduced, the host refines), a spin-block system, more than 512 orbitals."""
+    from .engine import Engine
+    F = np.asarray(F)
+    S = np.asarray(S)
+    if not hasattr(g, "_negf_lower") or _dist.is_active() or _split_depth or F.shape[0] > Engine.REFINE_MAX_N:
+        return None
+    if _spin_split(F, S, g) is not None:
+        return None
+
+    def refine(requests, tol):
+        assert len(requests) <= Engine.REFINE_MAX_INTEGRALS and sum(len(lv) for lv, _ in requests) <= Engine.REFINE_MAX_LEVELS
+        for levels, _ in requests:
+            for E, w, _ in levels:
+                _check(F, S, np.asarray(E), np.asarray(w))
+        engine = get_engine()
+        engine.set_system(F, S)
+        return engine.gr_int_refine(g._negf_lower(engine), requests, tol)
+    return refine
+
+
 def GrLessIntSegments(F, S, g, segments, ind=None):
     """``[GrLessInt(F, S, g, E, w, ind) for (E, w) in segments]`` from one pass of the engine (negf_gless_int_seg /
     negf_gless_int_seg_dev); a plain loop under the same conditions as GrIntSegments."""

@@ -170,6 +170,18 @@ int negf_gr_int(negf_ctx* ctx, int handle, int m, const double* E_c128,
 int negf_gr_int_seg(negf_ctx* ctx, int handle, int m, const double* E_c128, const double* w_c128,
                     int nseg, const int* seg_end, double* out_c128, int* info);
 
+/* integratePointsAdaptiveANT (density.py:211-273) with the refinement on the device.  The m energies are the NEW nodes of
+ * consecutive levels of nint adaptive integrations of one system: nlev[k] levels for integration k, seg_end[s] as above over all
+ * sum(nlev) levels (integration after integration), ratio[s] = the nested-weight ratio of level s (density.py:248-252) -- NaN
+ * for the first level of an integration (P = that level's sum, no test); an integration whose first ratio is a number continues
+ * from P_in[k].  Per level, in the reference's order: new_P = P * ratio; new_P += sum; maxDP = max|new_P - P|; stop when
+ * maxDP < tol (density.py:253-268).  P_out [nint][n][n]: the value at the converged level or after the last one; level_out [nint]:
+ * index of the converged level within the call or -1 (continue with P_out as P_in); maxdp_out [sum(nlev)] (NaN: level not
+ * consumed / first level).  n <= 512, nint <= 64. */
+int negf_gr_int_refine(negf_ctx* ctx, int handle, int m, const double* E_c128, const double* w_c128, int nint,
+                       const int* nlev, const int* seg_end, const double* ratio, double tol, const double* P_in_c128,
+                       double* P_out_c128, int* level_out, double* maxdp_out, int* info);
+
 /* ... and the same for GrLessInt: the levels of the adaptive bias-window integral (densityGrid, density.py:605-658). */
 int negf_gless_int_seg(negf_ctx* ctx, int handle, int ind, int m, const double* E_c128, const double* w_c128,
                        int nseg, const int* seg_end, double* out_c128, int* info);

@@ -68,6 +68,51 @@ def test_speculative_and_joint_refinement_equal_the_reference_loop(tol):
                 assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d), (tol, budget)
 
 
+def _host_refine(requests, tol):
+    """negf_gr_int_refine's contract, restated on the host (what Engine.gr_int_refine returns)."""
+    out = []
+    for levels, P in requests:
+        conv, maxdps = -1, []
+        for j, (E, w, ratio) in enumerate(levels):
+            val = _integrand(E, w)
+            if ratio is None:
+                assert j == 0 and P is None
+                P = val; maxdps.append(np.nan)
+                continue
+            new_P = P * ratio
+            new_P += val
+            maxdps.append(np.max(np.abs(new_P - P)))
+            P = new_P
+            if maxdps[-1] < tol:
+                conv = j
+                break
+        out.append((P, conv, np.array(maxdps + [np.nan] * (len(levels) - len(maxdps)))))
+    return out
+
+
+@pytest.mark.parametrize("tol", [1e-3, 1e-6, 1e-9, 1e-30])
+def test_device_side_refinement_driver_equals_the_reference_loop(tol):
+    """density._refine_jointly (the refinement itself delegated to negf_gr_int_refine, here restated on the host): the same
+    values, the same stopping level and the same messages as the reference loop, whatever the budget -- including
+    integrations that need a second round with their running value handed back in."""
+    out_ref, out_new = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(out_ref):
+        ref = [_reference_driver(lambda x, w, m=m: _integrand(*m(x, w)), tol) for m in MAPS]
+        D.integrateJointlyAdaptiveANT(MAPS, lambda segs: [_integrand(E, w) for E, w in segs], tol=tol, budget=0)
+    rounds = []
+
+    def refine(requests, tol_):
+        rounds.append([len(lv) for lv, _ in requests])
+        return _host_refine(requests, tol_)
+    for budget in (0, 6, 64, 512):
+        with contextlib.redirect_stdout(out_new if budget == 0 else io.StringIO()):
+            got = D._refine_jointly(MAPS, refine, tol=tol, budget=budget)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), (tol, budget)
+    assert out_new.getvalue() == out_ref.getvalue()
+    assert max(len(r) for r in rounds) == 2 and any(r == [6, 6] for r in rounds)     # budget 512: every level in one round
+
+
 def test_joint_refinement_batches_requests():
     """Two integrations that converge at different levels: every round is ONE call carrying the requests of those still
     refining; the one that has converged asks for nothing more."""

@@ -372,6 +372,69 @@ def test_segments_on_the_windowed_inverse_and_on_spin_blocks(engine):
         assert rel_fro(a, GrLessInt(F2, S2, g2, E, w, -1)) < 1e-12
 
 
+@pytest.mark.parametrize("N", [24, 60, 130, 300])
+def test_refinement_on_the_device_equals_the_host_refinement(engine, N, capsys):
+    """negf_gr_int_refine: the nested-rule update and stopping test of density.py:239-268 run by the library on the level sums
+    it has just computed.  Against the host refinement of the same sums (Engine.gr_int_seg + numpy): the same value BITWISE
+    at the same level, the same maxDP per level to an ulp of hypot; an integration that does not converge in its first call
+    continues from its running value; densityComplex gives the same density and the same messages with the switch on and
+    off, and agrees with the oracle-served integration."""
+    from gaunegf_amd import density as D
+    F, S, g, g_ref = _const(N, 300 + N)
+    engine.set_system(F, S)
+    h = g._negf_lower(engine)
+    levels = D._ant_levels(486)
+    half_width, mid, radius = D._contour(-3.0, 0.2, 300.0)
+    arc = lambda x, w: (mid + radius * np.exp(1j * (np.pi / 2 * (x + 1))), np.pi / 2 * w * (1j * radius * np.exp(1j * (np.pi / 2 * (x + 1)))))
+    tail = lambda x, w: (half_width * x + 0.2 + 0j, half_width * w + 0j)
+    for tol in (1e-3, 1e-6, 1e-30):
+        # host refinement on the segment sums
+        want = []
+        for grid in (arc, tail):
+            sums = engine.gr_int_seg(h, [grid(lv[1], lv[2]) for lv in levels])
+            P, conv, dps = sums[0].copy(), -1, [np.nan]
+            for j in range(1, len(levels)):
+                new_P = P * levels[j][3]
+                new_P += sums[j]
+                dps.append(np.max(np.abs(new_P - P)))
+                P = new_P
+                if dps[-1] < tol:
+                    conv = j
+                    break
+            want.append((P, conv, dps))
+        # one call, all levels, both integrals
+        got = engine.gr_int_refine(h, [([grid(lv[1], lv[2]) + (lv[3],) for lv in levels], None) for grid in (arc, tail)], tol)
+        for (P, conv, dps), (Pd, convd, dpsd) in zip(want, got):
+            assert convd == conv and np.array_equal(Pd, P)
+            assert np.allclose(dpsd[1:len(dps)], dps[1:], rtol=1e-14, atol=0) and np.all(np.isnan(dpsd[len(dps):])) and np.isnan(dpsd[0])
+        # two calls: levels 0..2, then the rest from the running value
+        first = engine.gr_int_refine(h, [([arc(lv[1], lv[2]) + (lv[3],) for lv in levels[:3]], None)], tol)[0]
+        if first[1] < 0:
+            second = engine.gr_int_refine(h, [([arc(lv[1], lv[2]) + (lv[3],) for lv in levels[3:]], first[0])], tol)[0]
+            # (the level sums of another call may be grouped differently in the workspace: rounding, not bits)
+            assert rel_fro(second[0], want[0][0]) < 1e-14 and (second[1] + 3 if second[1] >= 0 else -1) == want[0][1]
+        else:
+            assert first[1] == want[0][1] and rel_fro(first[0], want[0][0]) < 1e-14
+    capsys.readouterr()
+    dens, text = {}, {}
+    for on in (True, False):
+        D.REFINE_ON_DEVICE = on
+        try:
+            dens[on] = D.densityComplex(F, S, g, -3.0, 0.2, tol=1e-6, T=300.0)
+        finally:
+            D.REFINE_ON_DEVICE = True
+        text[on] = capsys.readouterr().out
+    assert text[True] == text[False] and "converged" in text[True]
+    assert rel_fro(dens[True], dens[False]) < 1e-14
+    saved = D.GrInt
+    D.GrInt = oracle.GrInt
+    try:
+        ref = D.densityComplex(F, S, g_ref, -3.0, 0.2, tol=1e-6, T=300.0)
+    finally:
+        D.GrInt = saved
+    assert rel_fro(dens[True], ref) < TOL
+
+
 def test_fixed_grid_density_step_in_one_pass(engine):
     """density.densityEquilibriumN = (densityRealN, densityComplexN) from one pass over the three grids; NEGFE.FockToP with
     fixed grids at a given Fermi level uses it and reproduces the oracle-served step."""
