@@ -67,7 +67,7 @@ def getANTPoints(N):
 
 
 SPECULATIVE_POINTS = 64      # new nodes evaluated per launch AHEAD of the convergence test (0: level by level);
-SPECULATIVE_POINTS_ONE_CU = 192  # ... for systems whose inverse is ONE workgroup per matrix (n <= 256): up to one matrix
+SPECULATIVE_POINTS_ONE_CU = int(os.environ.get("NEGF_SPECULATIVE_ONE_CU", "192"))  # ... for systems whose inverse is ONE workgroup per matrix (n <= 256): up to one matrix
                                  # per compute unit a launch takes what a single matrix does (n = 200: 2 points 0.61 ms,
                                  # 108 points 0.68 ms, 324 points 1.44 ms) -- levels 2 ... 162 in one go
 SPECULATIVE_POINTS_SMALL = int(os.environ.get("NEGF_SPECULATIVE_SMALL", "512"))   # ... and for n <= 96 (matrix in registers, several per compute unit; n = 60: 2 points
