@@ -232,12 +232,29 @@ def integrateJointlyAdaptiveANT(node_grids, computeSegments, tol=ADAPTIVE_INTEGR
 REFINE_ON_DEVICE = os.environ.get("NEGF_REFINE_ON_DEVICE", "1") != "0"   # adaptive GrInt integrations: update + stopping test in the library
 
 
+_LEVEL_GROUPS = {}
+
+
+def _level_group(maxN, lo, hi):
+    """Levels lo ... hi-1 of the nested rule as ONE node array: (nodes, weights, nodes per level, ratio per level), read-only,
+    built once.  A grid map applied to it evaluates all those levels in one go -- every map is elementwise, so each node gets
+    the value it gets level by level (twelve small numpy pipelines per Fermi probe become two)."""
+    key = (maxN, lo, hi)
+    if key not in _LEVEL_GROUPS:
+        lv = _ant_levels(maxN)[lo:hi]
+        x = np.concatenate([l[1] for l in lv]); w = np.concatenate([l[2] for l in lv])
+        x.setflags(write=False); w.setflags(write=False)
+        _LEVEL_GROUPS[key] = (x, w, tuple(l[1].size for l in lv), tuple(l[3] for l in lv))
+    return _LEVEL_GROUPS[key]
+
+
 def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, budget=None):
     """integrateJointlyAdaptiveANT with the refinement itself on the device: every round hands the levels each integration
     is about to visit (up to ``budget`` new nodes, as _adaptive_ant_steps groups them) to ``refine`` -- ONE pass of the
     engine, which applies the reference's update and stopping test level by level (density.py:239-268) and returns the value
     at the level that converged, or after the last one together with the fact that it did not.  What the host no longer does:
-    receive a sum per level and run five numpy passes over each.  Messages as in _adaptive_ant_steps."""
+    receive a sum per level and run five numpy passes over each.  ``refine`` takes [(E, w, nodes per level, ratio per level,
+    running value or None)] (Engine.gr_int_refine).  Messages as in _adaptive_ant_steps."""
     levels = _ant_levels(maxN)
     if budget is None:
         budget = SPECULATIVE_POINTS
@@ -247,23 +264,22 @@ def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_G
     while active:
         groups, requests = [], []
         for k in active:
-            group, pts = [], 0
-            for j in range(nxt[k], len(levels)):
-                if group and pts + levels[j][1].size > budget:
-                    break
-                group.append(j); pts += levels[j][1].size
-            groups.append(group)
-            requests.append(([node_grids[k](levels[j][1], levels[j][2]) + (levels[j][3],) for j in group], running[k]))
+            hi, pts = nxt[k], 0
+            while hi < len(levels) and (hi == nxt[k] or pts + levels[hi][1].size <= budget):
+                pts += levels[hi][1].size; hi += 1
+            x, w, counts, ratios = _level_group(maxN, nxt[k], hi)
+            groups.append((nxt[k], hi))
+            requests.append(node_grids[k](x, w) + (counts, ratios, running[k]))
         still = []
-        for k, group, (value, conv, maxdps) in zip(active, groups, refine(requests, tol)):
+        for k, (lo, hi), (value, conv, maxdps) in zip(active, groups, refine(requests, tol)):
             if conv >= 0:
-                print(f'Adaptive integration converged to {maxdps[conv]:.3e} in {levels[group[conv]][0]} points.')
+                print(f'Adaptive integration converged to {maxdps[conv]:.3e} in {levels[lo + conv][0]} points.')
                 result[k] = value
-            elif group[-1] == len(levels) - 1:
+            elif hi == len(levels):
                 print(f'Adaptive integration reached full grid ({levels[-1][0] / 1} points), final error {maxdps[-1]:.3e}')
                 result[k] = value
             else:
-                running[k], nxt[k] = value, group[-1] + 1
+                running[k], nxt[k] = value, hi
                 still.append(k)
         active = still
     return result
@@ -491,6 +507,7 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
     captured grids are compared bit for bit, tests/test_grids.py)."""
     half_width, mid, radius = _contour(Emin, mu, T)
     quarter_turn = np.pi / 2
+    budget = _speculation_budget(F, S, g) if GrInt is _ENGINE_GRINT else 0      # (once per call: it checks the system's structure)
 
     def on_arc(x, w):
         phase = np.exp(1j * (quarter_turn * (x + 1)))
@@ -510,26 +527,26 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
         return integratePointsAdaptiveANT(lambda x, w: GrInt(F, S, g, *grid(x, w)), tol=tol, debug=debug,
                                           computeLevels=(lambda nodes: GrIntSegments(F, S, g, [grid(x, w) for x, w in nodes]))
                                           if GrInt is _ENGINE_GRINT else None,
-                                          budget=_speculation_budget(F, S, g))
+                                          budget=budget)
 
-    fused = GrInt is _ENGINE_GRINT and not debug and _speculation_budget(F, S, g) > 0
+    fused = GrInt is _ENGINE_GRINT and not debug and budget > 0
     refine = _integrate.GrIntRefiner(F, S, g) if fused and REFINE_ON_DEVICE else None
     if T > 0 and fused:
         # the contour and the Fermi tail refine together: one launch per round for both (integrateJointlyAdaptiveANT; where
         # the library can run the refinement itself, _refine_jointly: only the refined values come back)
         print('Complex Contour Integration (with the Fermi broadening):')
         if refine is not None:
-            total, tail = _refine_jointly([grid_of(on_arc), grid_of(on_tail)], refine, tol=tol, budget=_speculation_budget(F, S, g))
+            total, tail = _refine_jointly([grid_of(on_arc), grid_of(on_tail)], refine, tol=tol, budget=budget)
             total = total + tail
         else:
             total, tail = integrateJointlyAdaptiveANT([grid_of(on_arc), grid_of(on_tail)],
                                                       lambda segs: GrIntSegments(F, S, g, segs), tol=tol,
-                                                      budget=_speculation_budget(F, S, g))
+                                                      budget=budget)
             total += tail
         return (1 + 0j) * np.imag(total) / np.pi
     print('Complex Contour Integration:')
     if refine is not None:
-        total = _refine_jointly([grid_of(on_arc)], refine, tol=tol, budget=_speculation_budget(F, S, g))[0]
+        total = _refine_jointly([grid_of(on_arc)], refine, tol=tol, budget=budget)[0]
     else:
         total = integral_over(on_arc)
     if T > 0:

@@ -321,43 +321,45 @@ class Engine:
     REFINE_MAX_INTEGRALS, REFINE_MAX_LEVELS = 64, 2048
 
     def gr_int_refine(self, handle, requests, tol):
-        """Nested adaptive refinement on the device (negf_gr_int_refine).  ``requests`` = [(levels, P_in)] per integral, with
-        ``levels`` = [(E, w, ratio)] the NEW nodes of consecutive levels of the nested rule (``ratio`` None for the first
-        level of an integration) and ``P_in`` the running value of an integration that continues (None otherwise).
-        Returns [(P, converged, maxdps)]: the value at the converged level (``converged`` = its index in ``levels``) or after
-        the last level (``converged`` = -1), and the maxDP of every level consumed (NaN for a first level)."""
-        Es, ws, ends, ratios, nlev = [], [], [], [], []
-        for levels, P_in in requests:
-            nlev.append(len(levels))
-            for j, (E, w, ratio) in enumerate(levels):
-                E = np.asarray(E).ravel(); w = np.asarray(w).ravel()
-                assert E.size == w.size, "Elist and weights must have the same length"
-                assert (ratio is None) == (j == 0 and P_in is None), "only the first level of a fresh integration has no ratio"
-                Es.append(E); ws.append(w); ratios.append(np.nan if ratio is None else float(ratio))
-                ends.append((ends[-1] if ends else 0) + E.size)
+        """Nested adaptive refinement on the device (negf_gr_int_refine).  ``requests`` = [(E, w, counts, ratios, P_in)] per
+        integral: ``E``, ``w`` the NEW nodes of consecutive levels of the nested rule, one after the other (``counts`` nodes
+        per level), ``ratios`` the nested-weight ratio of each level (None for the first level of a fresh integration) and
+        ``P_in`` the running value of an integration that continues (None otherwise).
+        Returns [(P, converged, maxdps)]: the value at the converged level (``converged`` = its index among the levels
+        handed in) or after the last level (``converged`` = -1), and the maxDP of every level consumed (NaN for a first level)."""
+        Es, ws, ends, rats, nlev, off = [], [], [], [], [], 0
+        for E, w, counts, ratios, P_in in requests:
+            E = np.asarray(E).ravel(); w = np.asarray(w).ravel()
+            assert E.size == w.size == sum(counts) and len(counts) == len(ratios), "levels do not add up to the grid"
+            assert all((r is None) == (j == 0 and P_in is None) for j, r in enumerate(ratios)), \
+                "only the first level of a fresh integration has no ratio"
+            Es.append(E); ws.append(w); nlev.append(len(counts))
+            for c, r in zip(counts, ratios):
+                off += int(c)
+                ends.append(off); rats.append(np.nan if r is None else float(r))
         E, w = self._grid(np.concatenate(Es), np.concatenate(ws))
         nint = len(requests)
         ends = np.ascontiguousarray(ends, dtype=np.int32)
         nlev = np.ascontiguousarray(nlev, dtype=np.int32)
-        ratios = np.ascontiguousarray(ratios, dtype=np.float64)
+        rats = np.ascontiguousarray(rats, dtype=np.float64)
         P_in = None
-        if any(P is not None for _, P in requests):
+        if any(r[4] is not None for r in requests):
             P_in = np.zeros((nint, self.n, self.n), dtype=np.complex128)
-            for k, (_, P) in enumerate(requests):
-                if P is not None:
-                    P_in[k] = P
+            for k, r in enumerate(requests):
+                if r[4] is not None:
+                    P_in[k] = r[4]
         out = np.empty((nint, self.n, self.n), dtype=np.complex128)
         level = np.zeros(nint, dtype=np.int32)
         maxdp = np.zeros(ends.size, dtype=np.float64)
         info = np.zeros(max(E.size, 1), dtype=np.int32)
         rc = check(self._lib.negf_gr_int_refine(self._ctx, handle, E.size, _ptr(E), _ptr(w), nint, _ptr(nlev), _ptr(ends),
-                                                _ptr(ratios), C.c_double(tol), _ptr(P_in), _ptr(out), _ptr(level), _ptr(maxdp),
+                                                _ptr(rats), C.c_double(tol), _ptr(P_in), _ptr(out), _ptr(level), _ptr(maxdp),
                                                 _ptr(info)), "negf_gr_int_refine")
         self._numerical(rc, info[:E.size], "gr_int_refine")
-        res, s = [], 0
+        res, s0 = [], 0
         for k in range(nint):
-            res.append((out[k], int(level[k]), maxdp[s:s + nlev[k]].copy()))
-            s += int(nlev[k])
+            res.append((out[k], int(level[k]), maxdp[s0:s0 + nlev[k]].copy()))
+            s0 += int(nlev[k])
         return res
 
     def gless_int_seg(self, handle, ind, segments):

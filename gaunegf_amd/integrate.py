@@ -303,10 +303,9 @@ def GrIntRefiner(F, S, g):
         return None
 
     def refine(requests, tol):
-        assert len(requests) <= Engine.REFINE_MAX_INTEGRALS and sum(len(lv) for lv, _ in requests) <= Engine.REFINE_MAX_LEVELS
-        for levels, _ in requests:
-            for E, w, _ in levels:
-                _check(F, S, np.asarray(E), np.asarray(w))
+        assert len(requests) <= Engine.REFINE_MAX_INTEGRALS and sum(len(r[2]) for r in requests) <= Engine.REFINE_MAX_LEVELS
+        for E, w, *_ in requests:
+            _check(F, S, np.asarray(E), np.asarray(w))
         engine = get_engine()
         engine.set_system(F, S)
         return engine.gr_int_refine(g._negf_lower(engine), requests, tol)

@@ -71,10 +71,11 @@ def test_speculative_and_joint_refinement_equal_the_reference_loop(tol):
 def _host_refine(requests, tol):
     """negf_gr_int_refine's contract, restated on the host (what Engine.gr_int_refine returns)."""
     out = []
-    for levels, P in requests:
-        conv, maxdps = -1, []
-        for j, (E, w, ratio) in enumerate(levels):
-            val = _integrand(E, w)
+    for E, w, counts, ratios, P in requests:
+        conv, maxdps, off = -1, [], 0
+        for j, (c, ratio) in enumerate(zip(counts, ratios)):
+            val = _integrand(E[off:off + c], w[off:off + c])
+            off += c
             if ratio is None:
                 assert j == 0 and P is None
                 P = val; maxdps.append(np.nan)
@@ -86,7 +87,7 @@ def _host_refine(requests, tol):
             if maxdps[-1] < tol:
                 conv = j
                 break
-        out.append((P, conv, np.array(maxdps + [np.nan] * (len(levels) - len(maxdps)))))
+        out.append((P, conv, np.array(maxdps + [np.nan] * (len(counts) - len(maxdps)))))
     return out
 
 
@@ -102,7 +103,7 @@ def test_device_side_refinement_driver_equals_the_reference_loop(tol):
     rounds = []
 
     def refine(requests, tol_):
-        rounds.append([len(lv) for lv, _ in requests])
+        rounds.append([len(r[2]) for r in requests])
         return _host_refine(requests, tol_)
     for budget in (0, 6, 64, 512):
         with contextlib.redirect_stdout(out_new if budget == 0 else io.StringIO()):
@@ -111,6 +112,43 @@ def test_device_side_refinement_driver_equals_the_reference_loop(tol):
             assert np.array_equal(a, b), (tol, budget)
     assert out_new.getvalue() == out_ref.getvalue()
     assert max(len(r) for r in rounds) == 2 and any(r == [6, 6] for r in rounds)     # budget 512: every level in one round
+
+
+def test_grids_of_the_refined_path_equal_the_level_by_level_grids_bitwise(monkeypatch):
+    """density._refine_jointly evaluates an integration's node -> energy map ONCE on the concatenated nodes of the levels it
+    requests.  Every map is elementwise: each node must get, bit for bit, the energy and the weight it gets when the levels are
+    mapped one by one (the reference's sequence, captured here through a GrInt that never converges)."""
+    N = 6
+    F = np.diag(np.linspace(-1.0, 1.0, N)); S = np.eye(N)
+    per_level = []
+
+    def fake_grint(F_, S_, g_, E, w):
+        per_level.append((np.array(E), np.array(w)))
+        return np.full((N, N), float(len(per_level) % 2) * 1e6, dtype=complex)      # max|dP| stays huge: every level is visited
+    monkeypatch.setattr(D, "GrInt", fake_grint)
+    with contextlib.redirect_stdout(io.StringIO()):
+        D.densityComplex(F, S, object(), -3.0, 0.2, tol=1e-6, T=300.0)
+    assert [e.size for e, _ in per_level] == [2, 4, 12, 36, 108, 324] * 2            # arc, then tail
+    monkeypatch.undo()
+    got = []
+
+    def fake_refiner(F_, S_, g_):
+        def refine(requests, tol):
+            got.extend(requests)
+            return [(np.zeros((N, N), dtype=complex), -1, np.full(len(r[2]), 1.0)) for r in requests]
+        return refine
+    monkeypatch.setattr(D._integrate, "GrIntRefiner", fake_refiner)
+    monkeypatch.setattr(D, "_speculation_budget", lambda *a: 512)
+    with contextlib.redirect_stdout(io.StringIO()):
+        D.densityComplex(F, S, object(), -3.0, 0.2, tol=1e-6, T=300.0)
+    assert len(got) == 2 and [r[2] for r in got] == [(2, 4, 12, 36, 108, 324)] * 2
+    for k, (E, w, counts, ratios, P_in) in enumerate(got):
+        off = 0
+        for j, c in enumerate(counts):
+            e_ref, w_ref = per_level[6 * k + j]
+            assert np.array_equal(E[off:off + c], e_ref) and np.array_equal(w[off:off + c], w_ref), (k, j)
+            off += c
+        assert ratios[0] is None and all(r is not None for r in ratios[1:]) and P_in is None
 
 
 def test_joint_refinement_batches_requests():

@@ -403,14 +403,17 @@ def test_refinement_on_the_device_equals_the_host_refinement(engine, N, capsys):
                     break
             want.append((P, conv, dps))
         # one call, all levels, both integrals
-        got = engine.gr_int_refine(h, [([grid(lv[1], lv[2]) + (lv[3],) for lv in levels], None) for grid in (arc, tail)], tol)
+        def request(grid, lo, hi, P_in):
+            x, w, counts, ratios = D._level_group(486, lo, hi)
+            return grid(x, w) + (counts, ratios, P_in)
+        got = engine.gr_int_refine(h, [request(grid, 0, 6, None) for grid in (arc, tail)], tol)
         for (P, conv, dps), (Pd, convd, dpsd) in zip(want, got):
             assert convd == conv and np.array_equal(Pd, P)
             assert np.allclose(dpsd[1:len(dps)], dps[1:], rtol=1e-14, atol=0) and np.all(np.isnan(dpsd[len(dps):])) and np.isnan(dpsd[0])
         # two calls: levels 0..2, then the rest from the running value
-        first = engine.gr_int_refine(h, [([arc(lv[1], lv[2]) + (lv[3],) for lv in levels[:3]], None)], tol)[0]
+        first = engine.gr_int_refine(h, [request(arc, 0, 3, None)], tol)[0]
         if first[1] < 0:
-            second = engine.gr_int_refine(h, [([arc(lv[1], lv[2]) + (lv[3],) for lv in levels[3:]], first[0])], tol)[0]
+            second = engine.gr_int_refine(h, [request(arc, 3, 6, first[0])], tol)[0]
             # (the level sums of another call may be grouped differently in the workspace: rounding, not bits)
             assert rel_fro(second[0], want[0][0]) < 1e-14 and (second[1] + 3 if second[1] >= 0 else -1) == want[0][1]
         else:
