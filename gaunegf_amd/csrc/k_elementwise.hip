@@ -6,6 +6,7 @@
 // All accesses are 16-byte (one complex128) per lane, consecutive lanes on
 // consecutive elements -> fully coalesced 1 KiB wave transactions.
 #include "negf_common.h"
+#include <algorithm>
 
 static constexpr int EW_THREADS = 256;
 
@@ -407,6 +408,61 @@ __global__ __launch_bounds__(1024) void refine_levels_kernel(int n2, const cplx*
         level_out[k] = conv;
         for (int s = s0 + (conv < 0 ? s1 - s0 : conv + 1); s < s1; ++s) maxdp_out[s] = qnan;   // levels not consumed
     }
+}
+
+// The same for matrices too large for one workgroup per integration (n > REF_MAX_N): one level = one launch of many
+// workgroups (update, block maxima folded into a 64-bit atomic maximum of the bit pattern -- |.| >= 0 orders like its bits) and
+// a one-thread decision kernel; a level launched after the integration has converged returns at once (conv >= 0), so the
+// whole walk is queued on the stream without a host round trip.
+__global__ __launch_bounds__(256) void refine_wide_kernel(int n2, const cplx* __restrict__ inc, double r, cplx* __restrict__ Pk,
+                                                          const int* __restrict__ conv, unsigned long long* __restrict__ maxbits,
+                                                          int* __restrict__ nanflag)
+{
+    if (*conv >= 0) return;
+    __shared__ double red[4];
+    __shared__ int red_nan[4];
+    double mx = 0.0;
+    int any_nan = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n2; i += gridDim.x * 256) {
+        const cplx p = Pk[i];
+        cplx q = cmake(p.x * r - p.y * 0.0, p.x * 0.0 + p.y * r);
+        const cplx v = inc[i];
+        q = cmake(q.x + v.x, q.y + v.y);
+        const double a = hypot(q.x - p.x, q.y - p.y);
+        if (a != a) any_nan = 1; else mx = a > mx ? a : mx;
+        Pk[i] = q;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(mx, off, 64);
+        mx = o > mx ? o : mx;
+        any_nan |= __shfl_down(any_nan, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = mx; red_nan[threadIdx.x >> 6] = any_nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q) { mx = red[q] > mx ? red[q] : mx; any_nan |= red_nan[q]; }
+        atomicMax(maxbits, (unsigned long long)__double_as_longlong(mx));
+        if (any_nan) atomicOr(nanflag, 1);
+    }
+}
+
+__global__ void refine_decide_kernel(int level_idx, double tol, const unsigned long long* __restrict__ maxbits,
+                                     const int* __restrict__ nanflag, int* __restrict__ conv, double* __restrict__ maxdp_slot)
+{
+    const double qnan = __builtin_nan("");
+    if (*conv >= 0) { *maxdp_slot = qnan; return; }               // level not consumed
+    const double maxdp = *nanflag ? qnan : __longlong_as_double((long long)*maxbits);
+    *maxdp_slot = maxdp;
+    if (maxdp < tol) *conv = level_idx;
+}
+
+void launch_refine_level_wide(hipStream_t st, int n2, const cplx* inc, double ratio, cplx* Pk, int level_idx, double tol,
+                              int* conv, unsigned long long* maxbits, int* nanflag, double* maxdp_slot)
+{
+    const int grid = std::min(2048, (n2 + 255) / 256);
+    hipLaunchKernelGGL(refine_wide_kernel, dim3(grid), dim3(256), 0, st, n2, inc, ratio, Pk, conv, maxbits, nanflag);
+    hipLaunchKernelGGL(refine_decide_kernel, dim3(1), dim3(1), 0, st, level_idx, tol, maxbits, nanflag, conv, maxdp_slot);
 }
 
 void launch_refine_levels(hipStream_t st, int n2, int nint, const cplx* sums, const int* first, const double* ratio, double tol,

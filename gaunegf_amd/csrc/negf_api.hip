@@ -1683,10 +1683,10 @@ int negf_gr_int_seg(negf_ctx* c, int handle, int m, const double* E, const doubl
 // are the NEW nodes of consecutive levels of nint integrations (nlev[k] levels each, seg_end as in negf_gr_int_seg over all
 // sum(nlev) levels, integral after integral); ratio[s] is the nested-weight ratio of level s -- NaN for the first level of an
 // integration, which then starts from that level's sum; otherwise the integration continues from P_in[k].  One pass evaluates
-// every level's sum, refine_levels_kernel runs the reference's update and stopping test level by level, and only the result comes
-// back: P_out [nint][n][n] (the value at the converged level, or after the last level), level_out [nint] (index of the
+// every level's sum, refine_levels_kernel (n > 512: one refine_wide_kernel launch per level) runs the reference's update and
+// stopping test level by level, and only the result comes back: P_out [nint][n][n] (the value at the converged level, or after the last level), level_out [nint] (index of the
 // converged level within the call, -1: not converged, continue with P_out as P_in), maxdp_out [sum(nlev)].  Saves the host the
-// level sums (12 x n^2 per Fermi probe), the five numpy passes per level over them, and their download.  n <= REF_MAX_N.
+// level sums (12 x n^2 per Fermi probe), the five numpy passes per level over them, and their download.
 int negf_gr_int_refine(negf_ctx* c, int handle, int m, const double* E, const double* w, int nint, const int* nlev,
                        const int* seg_end, const double* ratio, double tol, const double* P_in, double* P_out,
                        int* level_out, double* maxdp_out, int* info)
@@ -1695,7 +1695,6 @@ int negf_gr_int_refine(negf_ctx* c, int handle, int m, const double* E, const do
     int rc = check_ready(c, p, m);
     if (rc) return rc;
     if (!P_out || !level_out || !maxdp_out || !nlev || !ratio || nint <= 0 || nint > REF_MAX_INTS || (m > 0 && (!E || !w))) return NEGF_EINVAL;
-    if (c->n > REF_MAX_N) return NEGF_EINVAL;
     int nseg = 0;
     std::vector<int> first(nint + 1, 0);
     for (int k = 0; k < nint; ++k) { if (nlev[k] <= 0) return NEGF_EINVAL; nseg += nlev[k]; first[k + 1] = nseg; }
@@ -1707,7 +1706,7 @@ int negf_gr_int_refine(negf_ctx* c, int handle, int m, const double* E, const do
     NEGF_HIP_CHECK(hipSetDevice(c->device));
     const size_t n2 = (size_t)c->n * c->n;
     const size_t gb = (size_t)m * sizeof(cplx), pb = (size_t)nint * n2 * sizeof(cplx);
-    const size_t meta_b = (size_t)REF_MAX_LEVELS * 16 + (size_t)(2 * REF_MAX_INTS + 1) * 4;
+    const size_t meta_b = (size_t)REF_MAX_LEVELS * 24 + (size_t)(2 * REF_MAX_INTS + 1 + REF_MAX_LEVELS) * 4;
     if ((rc = ensure_pinned(c, 2 * gb + pb + meta_b + (size_t)m * sizeof(int) + 256))) return rc;
     if ((rc = stage_grid(c, m, p->n_contacts, E, w))) return rc;
     if ((size_t)nseg * n2 > c->seg_out_cap) {
@@ -1728,13 +1727,15 @@ int negf_gr_int_refine(negf_ctx* c, int handle, int m, const double* E, const do
     unsigned char* pmeta = pP + pb;
     double* h_ratio = reinterpret_cast<double*>(pmeta);
     double* h_maxdp = h_ratio + REF_MAX_LEVELS;
-    int* h_first = reinterpret_cast<int*>(h_maxdp + REF_MAX_LEVELS);
+    int* h_first = reinterpret_cast<int*>(h_maxdp + 2 * REF_MAX_LEVELS);          // (the host side mirrors the device layout)
     int* h_level = h_first + REF_MAX_INTS + 1;
-    int* pinfo = h_level + REF_MAX_INTS;
+    int* pinfo = h_level + REF_MAX_INTS + REF_MAX_LEVELS;
     double* d_ratio = reinterpret_cast<double*>(c->d_ref_meta);
     double* d_maxdp = d_ratio + REF_MAX_LEVELS;
-    int* d_first = reinterpret_cast<int*>(d_maxdp + REF_MAX_LEVELS);
+    unsigned long long* d_maxbits = reinterpret_cast<unsigned long long*>(d_maxdp + REF_MAX_LEVELS);
+    int* d_first = reinterpret_cast<int*>(d_maxbits + REF_MAX_LEVELS);
     int* d_level = d_first + REF_MAX_INTS + 1;
+    int* d_nanflag = d_level + REF_MAX_INTS;
     std::memcpy(h_ratio, ratio, (size_t)nseg * sizeof(double));
     std::memcpy(h_first, first.data(), (size_t)(nint + 1) * sizeof(int));
     NEGF_HIP_CHECK(hipMemcpyAsync(d_ratio, h_ratio, (size_t)nseg * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1748,7 +1749,25 @@ int negf_gr_int_refine(negf_ctx* c, int handle, int m, const double* E, const do
     if ((rc = gr_seg_core(c, p, m, c->d_E, c->d_w, nseg, seg_end, c->d_seg_out))) return rc;
     {
         ProfScope ps(c, "accumulate");
-        launch_refine_levels(c->stream, (int)n2, nint, c->d_seg_out, d_first, d_ratio, tol, c->d_ref_P, d_level, d_maxdp);
+        if (c->n <= REF_MAX_N) {
+            launch_refine_levels(c->stream, (int)n2, nint, c->d_seg_out, d_first, d_ratio, tol, c->d_ref_P, d_level, d_maxdp);
+        } else {
+            // one launch pair per level, queued without a host round trip (refine_wide_kernel)
+            NEGF_HIP_CHECK(hipMemsetAsync(d_maxbits, 0, (size_t)nseg * sizeof(unsigned long long), c->stream));
+            NEGF_HIP_CHECK(hipMemsetAsync(d_nanflag, 0, (size_t)nseg * sizeof(int), c->stream));
+            NEGF_HIP_CHECK(hipMemsetAsync(d_level, 0xFF, (size_t)nint * sizeof(int), c->stream));            // -1: not converged
+            NEGF_HIP_CHECK(hipMemsetAsync(d_maxdp, 0xFF, (size_t)nseg * sizeof(double), c->stream));         // all-ones: a NaN
+            for (int k = 0; k < nint; ++k)
+                for (int s = first[k]; s < first[k + 1]; ++s) {
+                    cplx* Pk = c->d_ref_P + (size_t)k * n2;
+                    const cplx* inc = c->d_seg_out + (size_t)s * n2;
+                    if (ratio[s] != ratio[s])
+                        NEGF_HIP_CHECK(hipMemcpyAsync(Pk, inc, n2 * sizeof(cplx), hipMemcpyDeviceToDevice, c->stream));
+                    else
+                        launch_refine_level_wide(c->stream, (int)n2, inc, ratio[s], Pk, s - first[k], tol, d_level + k,
+                                                 d_maxbits + s, d_nanflag + s, d_maxdp + s);
+                }
+        }
     }
     NEGF_HIP_CHECK(hipGetLastError());
     NEGF_HIP_CHECK(hipMemcpyAsync(pP, c->d_ref_P, pb, hipMemcpyDeviceToHost, c->stream));

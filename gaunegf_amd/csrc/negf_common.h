@@ -222,7 +222,7 @@ struct negf_ctx {
     size_t seg_out_cap = 0;
     cplx* d_ref_P = nullptr;       // [integrals][n*n] running values of negf_gr_int_refine
     size_t ref_P_cap = 0;
-    unsigned char* d_ref_meta = nullptr;   // its level table: ratio[REF_MAX_LEVELS] | maxdp[REF_MAX_LEVELS] | first[REF_MAX_INTS + 1] | level[REF_MAX_INTS]
+    unsigned char* d_ref_meta = nullptr;   // its level table: ratio | maxdp | maxbits [REF_MAX_LEVELS each] | first[REF_MAX_INTS + 1] | level[REF_MAX_INTS] | nanflag[REF_MAX_LEVELS]
     cplx* d_small_part = nullptr;  // per-workgroup partial sums of the small fused kernel
     size_t small_part_cap = 0;
     GjSideStreams gj_side;
@@ -289,6 +289,8 @@ void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const 
 constexpr int REF_MAX_LEVELS = 2048, REF_MAX_INTS = 64, REF_MAX_N = 512;
 void launch_refine_levels(hipStream_t st, int n2, int nint, const cplx* sums, const int* first, const double* ratio, double tol,
                           cplx* P, int* level_out, double* maxdp_out);
+void launch_refine_level_wide(hipStream_t st, int n2, const cplx* inc, double ratio, cplx* Pk, int level_idx, double tol,
+                              int* conv, unsigned long long* maxbits, int* nanflag, double* maxdp_slot);
 void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cplx* out);
 size_t accumulate_scratch_elems(int n2, int nb);
 

@@ -317,7 +317,7 @@ class Engine:
         self._numerical(rc, info[:E.size], "gr_int_seg")
         return [out[k] for k in range(len(segments))]
 
-    REFINE_MAX_N = 512                                            # negf_gr_int_refine: one workgroup walks an integral's levels
+    REFINE_MAX_N = 4096                                           # negf_gr_int_refine up to here (n <= 512: one workgroup walks an integral's levels; above: a launch per level); beyond, the running values alone are GBs
     REFINE_MAX_INTEGRALS, REFINE_MAX_LEVELS = 64, 2048
 
     def gr_int_refine(self, handle, requests, tol):

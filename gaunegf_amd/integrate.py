@@ -293,7 +293,7 @@ def GrIntRefiner(F, S, g):
     """``refine(requests, tol)`` -- the nested adaptive refinement of one or several GrInt integrals of this system with the
     update and the stopping test ON THE DEVICE (Engine.gr_int_refine / negf_gr_int_refine: the level sums never leave HBM,
     only the refined value comes back) -- or None where that form does not apply: a provider evaluated on the host, an
-    energy-sharded run (the level sums are all-reduced, the host refines), a spin-block system, more than 512 orbitals."""
+    energy-sharded run (the level sums are all-reduced, the host refines), a spin-block system, more than 4096 orbitals."""
     from .engine import Engine
     F = np.asarray(F)
     S = np.asarray(S)

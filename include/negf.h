@@ -177,7 +177,7 @@ int negf_gr_int_seg(negf_ctx* ctx, int handle, int m, const double* E_c128, cons
  * from P_in[k].  Per level, in the reference's order: new_P = P * ratio; new_P += sum; maxDP = max|new_P - P|; stop when
  * maxDP < tol (density.py:253-268).  P_out [nint][n][n]: the value at the converged level or after the last one; level_out [nint]:
  * index of the converged level within the call or -1 (continue with P_out as P_in); maxdp_out [sum(nlev)] (NaN: level not
- * consumed / first level).  n <= 512, nint <= 64. */
+ * consumed / first level).  nint <= 64, at most 2048 levels in all. */
 int negf_gr_int_refine(negf_ctx* ctx, int handle, int m, const double* E_c128, const double* w_c128, int nint,
                        const int* nlev, const int* seg_end, const double* ratio, double tol, const double* P_in_c128,
                        double* P_out_c128, int* level_out, double* maxdp_out, int* info);

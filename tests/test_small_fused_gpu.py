@@ -372,7 +372,7 @@ def test_segments_on_the_windowed_inverse_and_on_spin_blocks(engine):
         assert rel_fro(a, GrLessInt(F2, S2, g2, E, w, -1)) < 1e-12
 
 
-@pytest.mark.parametrize("N", [24, 60, 130, 300])
+@pytest.mark.parametrize("N", [24, 60, 130, 300, 600])       # (600: above 512 orbitals a launch per level instead of one workgroup per integration)
 def test_refinement_on_the_device_equals_the_host_refinement(engine, N, capsys):
     """negf_gr_int_refine: the nested-rule update and stopping test of density.py:239-268 run by the library on the level sums
     it has just computed.  Against the host refinement of the same sums (Engine.gr_int_seg + numpy): the same value BITWISE
@@ -390,8 +390,10 @@ def test_refinement_on_the_device_equals_the_host_refinement(engine, N, capsys):
     for tol in (1e-3, 1e-6, 1e-30):
         # host refinement on the segment sums
         want = []
-        for grid in (arc, tail):
-            sums = engine.gr_int_seg(h, [grid(lv[1], lv[2]) for lv in levels])
+        # (ONE pass over both integrations' levels, as the refining call makes it: the same level sums to the bit)
+        all_sums = engine.gr_int_seg(h, [grid(lv[1], lv[2]) for grid in (arc, tail) for lv in levels])
+        for k in range(2):
+            sums = all_sums[6 * k:6 * k + 6]
             P, conv, dps = sums[0].copy(), -1, [np.nan]
             for j in range(1, len(levels)):
                 new_P = P * levels[j][3]
