@@ -27,11 +27,16 @@ def timed(obj, name, label):
     setattr(obj, name, wrapper)
 
 
-for name in ("set_system", "gr_int", "gr_int_seg", "gless_int", "gless_int_seg", "dos", "sigma_const"):
+for name in ("set_system", "gr_int", "gr_int_seg", "gr_int_refine", "gless_int", "gless_int_seg", "dos", "sigma_const"):
     timed(eng, name, "engine." + name)
 for name in ("eigvals", "eigh", "eig", "inv", "solve"):
     timed(np.linalg, name, "numpy.linalg." + name)
 timed(DN, "fermi", "density.fermi"); timed(DN, "_speculation_budget", "density._speculation_budget")
+for name in ("densityReal", "densityGrid", "densityComplex", "calcEmin"):
+    timed(DN, name, "density." + name)
+import gaunegf_amd.scfE as _SC
+for name in ("densityReal", "densityGrid", "densityComplex", "calcEmin", "calcFermiMuller", "calcFermiBisect"):
+    timed(_SC, name, "scfE->" + name)
 limits = bench._blas_limits()
 with (limits(limits=16) if limits else contextlib.nullcontext()):
     for name in names:
