@@ -217,11 +217,19 @@ void launch_cadd(hipStream_t st, size_t count, const cplx* a, const cplx* b, cpl
 // batch at HBM rate (a single pass over i alone launches only n^2/256 workgroups).
 static constexpr int ACC_CHUNK = 32;
 
+// chunk table of a launch that serves SEVERAL sums at once (the segments of negf_gr_int_seg inside one workspace batch): chunk c
+// covers the matrices [b0[c], b1[c]) and writes partial record c; segment s owns the chunks [first[s], first[s + 1]) and adds
+// them, in order, to out + slot[s] * n2 -- the chunks of each segment are what launch_accumulate[_perm] would cut for it alone,
+// so every sum keeps its bits; nchunks == 0: the regular cut of one sum (blockIdx.y * ACC_CHUNK).
+static constexpr int ACC_TAB_CHUNKS = 96, ACC_TAB_SEGS = 32;
+struct AccChunks { int nchunks, nseg; int b0[ACC_TAB_CHUNKS], b1[ACC_TAB_CHUNKS]; int first[ACC_TAB_SEGS + 1], slot[ACC_TAB_SEGS]; };
+
 __global__ __launch_bounds__(EW_THREADS) void accumulate_partial_kernel(
-    int n2, int nb, const cplx* __restrict__ w, const cplx* __restrict__ X, cplx* __restrict__ part)
+    int n2, int nb, const cplx* __restrict__ w, const cplx* __restrict__ X, cplx* __restrict__ part, const AccChunks tab)
 {
     const int i = blockIdx.x * EW_THREADS + threadIdx.x;
-    const int b0 = blockIdx.y * ACC_CHUNK, b1 = min(nb, b0 + ACC_CHUNK);
+    const int b0 = tab.nchunks ? tab.b0[blockIdx.y] : blockIdx.y * ACC_CHUNK;
+    const int b1 = tab.nchunks ? tab.b1[blockIdx.y] : min(nb, b0 + ACC_CHUNK);
     if (i >= n2) return;
     cplx a = cmake(0.0, 0.0);
     int b = b0;
@@ -242,6 +250,17 @@ __global__ __launch_bounds__(EW_THREADS) void accumulate_final_kernel(
     if (i >= n2) return;
     cplx a = acc[i];
     for (int c = 0; c < nchunks; ++c) a = cadd(a, part[(size_t)c * n2 + i]);
+    acc[i] = a;
+}
+
+__global__ __launch_bounds__(EW_THREADS) void accumulate_final_seg_kernel(
+    int n2, const AccChunks tab, const cplx* __restrict__ part, cplx* __restrict__ out)
+{
+    const int i = blockIdx.x * EW_THREADS + threadIdx.x, sg = blockIdx.y;
+    if (i >= n2) return;
+    cplx* acc = out + (size_t)tab.slot[sg] * n2;
+    cplx a = acc[i];
+    for (int c = tab.first[sg]; c < tab.first[sg + 1]; ++c) a = cadd(a, part[(size_t)c * n2 + i]);
     acc[i] = a;
 }
 
@@ -281,12 +300,13 @@ __global__ __launch_bounds__(EW_THREADS) void accumulate_perm_partial_kernel(
 static constexpr int APR_MAXN = 2048;
 __global__ __launch_bounds__(EW_THREADS) void accumulate_perm_rows_kernel(
     int n, int nb, const cplx* __restrict__ w, const cplx* __restrict__ W, const int* __restrict__ piv,
-    const int* __restrict__ info, cplx* __restrict__ part)
+    const int* __restrict__ info, cplx* __restrict__ part, const AccChunks tab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char apr_raw[];
     cplx* rowbuf = reinterpret_cast<cplx*>(apr_raw);                      // [2][n]
     const int i = blockIdx.x, n2 = n * n;
-    const int b0 = blockIdx.y * ACC_CHUNK, b1 = min(nb, b0 + ACC_CHUNK);
+    const int b0 = tab.nchunks ? tab.b0[blockIdx.y] : blockIdx.y * ACC_CHUNK;
+    const int b1 = tab.nchunks ? tab.b1[blockIdx.y] : min(nb, b0 + ACC_CHUNK);
     const int tid = threadIdx.x;
     constexpr int CPT = APR_MAXN / EW_THREADS;                            // columns per thread
     const double qnan = __builtin_nan("");
@@ -330,10 +350,40 @@ void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const 
     static int rows = -1;
     if (rows < 0) { const char* e = getenv("NEGF_ACC_PERM_ROWS"); rows = e ? atoi(e) : 1; }
     if (rows && n <= APR_MAXN)
-        hipLaunchKernelGGL(accumulate_perm_rows_kernel, dim3(n, nchunks), dim3(EW_THREADS), (size_t)2 * n * sizeof(cplx), st, n, nb, w, W, piv, info, part);
+        hipLaunchKernelGGL(accumulate_perm_rows_kernel, dim3(n, nchunks), dim3(EW_THREADS), (size_t)2 * n * sizeof(cplx), st, n, nb, w, W, piv, info, part, AccChunks{});
     else
         hipLaunchKernelGGL(accumulate_perm_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n, nb, w, W, piv, info, part);
     hipLaunchKernelGGL(accumulate_final_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nchunks, part, acc);
+}
+
+// Several sums over sub-ranges of ONE workspace batch in one launch pair: range r = matrices [lo[r], hi[r]) of the batch (w, info,
+// X / W, piv all indexed from the batch's first matrix) is added to out + slot[r] * n2.  `perm`: the matrices are the windowed
+// inverse's reduced form (W, piv) instead of G (X).  Returns false when the table does not hold the request (the caller then
+// launches range by range).  `part` must hold one record per chunk (at most one per matrix of the batch).
+bool launch_accumulate_ranges(hipStream_t st, int n, bool perm, const cplx* w, const cplx* XW, const int* piv, const int* info,
+                              int nranges, const int* lo, const int* hi, const int* slot, cplx* out, cplx* part)
+{
+    static int rows = -1;
+    if (rows < 0) { const char* e = getenv("NEGF_ACC_PERM_ROWS"); rows = e ? atoi(e) : 1; }
+    if (nranges > ACC_TAB_SEGS || (perm && !(rows && n <= APR_MAXN))) return false;
+    AccChunks tab{};
+    for (int r = 0; r < nranges; ++r) {
+        tab.first[r] = tab.nchunks; tab.slot[r] = slot[r];
+        for (int b = lo[r]; b < hi[r]; b += ACC_CHUNK) {
+            if (tab.nchunks == ACC_TAB_CHUNKS) return false;
+            tab.b0[tab.nchunks] = b; tab.b1[tab.nchunks] = std::min(hi[r], b + ACC_CHUNK); ++tab.nchunks;
+        }
+    }
+    tab.first[nranges] = tab.nchunks; tab.nseg = nranges;
+    if (tab.nchunks == 0) return true;
+    const int n2 = n * n;
+    const int g = (n2 + EW_THREADS - 1) / EW_THREADS;
+    if (perm)
+        hipLaunchKernelGGL(accumulate_perm_rows_kernel, dim3(n, tab.nchunks), dim3(EW_THREADS), (size_t)2 * n * sizeof(cplx), st, n, 0, w, XW, piv, info, part, tab);
+    else
+        hipLaunchKernelGGL(accumulate_partial_kernel, dim3(g, tab.nchunks), dim3(EW_THREADS), 0, st, n2, 0, w, XW, part, tab);
+    hipLaunchKernelGGL(accumulate_final_seg_kernel, dim3(g, nranges), dim3(EW_THREADS), 0, st, n2, tab, part, out);
+    return true;
 }
 
 // `part` must hold ceil(nb / ACC_CHUNK) * n2 elements
@@ -343,7 +393,7 @@ void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx
 {
     const int g = (n2 + EW_THREADS - 1) / EW_THREADS;
     const int nchunks = (nb + ACC_CHUNK - 1) / ACC_CHUNK;
-    hipLaunchKernelGGL(accumulate_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n2, nb, w, X, part);
+    hipLaunchKernelGGL(accumulate_partial_kernel, dim3(g, nchunks), dim3(EW_THREADS), 0, st, n2, nb, w, X, part, AccChunks{});
     hipLaunchKernelGGL(accumulate_final_kernel, dim3(g), dim3(EW_THREADS), 0, st, n2, nchunks, part, acc);
 }
 

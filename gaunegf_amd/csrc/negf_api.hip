@@ -1619,6 +1619,17 @@ static int gr_seg_core(negf_ctx* c, SigmaProvider* p, int m, const cplx* Ed, con
             const bool perm = c->G_deferred;
             c->G_deferred = false;
             ProfScope ps(c, "accumulate");
+            {
+                // every segment's share of this batch in ONE launch pair (a joint arc + tail probe: 12 segments = 24 launches
+                // of a few microseconds each behind a millisecond of inverse)
+                std::vector<int> rlo, rhi, rslot;
+                for (int sg = 0, start = 0; sg < nseg; start = seg_end[sg], ++sg) {
+                    const int lo = std::max(start, m0), hi = std::min(seg_end[sg], m0 + nb);
+                    if (hi > lo) { rlo.push_back(lo - m0); rhi.push_back(hi - m0); rslot.push_back(sg); }
+                }
+                if (launch_accumulate_ranges(c->stream, c->n, perm, wd + m0, perm ? c->W1 : c->G, c->d_ipiv, c->d_info + m0,
+                                             (int)rlo.size(), rlo.data(), rhi.data(), rslot.data(), out, c->W2)) continue;
+            }
             for (int sg = 0, start = 0; sg < nseg; start = seg_end[sg], ++sg) {
                 const int lo = std::max(start, m0), hi = std::min(seg_end[sg], m0 + nb);
                 if (hi <= lo) continue;

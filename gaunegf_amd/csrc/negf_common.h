@@ -285,6 +285,8 @@ void launch_accumulate(hipStream_t st, int n2, int nb, const cplx* w, const cplx
 // the same sum over matrices still in their reduced, un-gathered form: X[b][i][j] = W[b][pivrow_b[i]][colof_b[j]] (piv = [nb][2][n];
 // a matrix with info[b] != 0 counts as NaN, as its gathered form would)
 void launch_accumulate_perm(hipStream_t st, int n, int nb, const cplx* w, const cplx* W, const int* piv, const int* info, cplx* acc, cplx* part);
+bool launch_accumulate_ranges(hipStream_t st, int n, bool perm, const cplx* w, const cplx* XW, const int* piv, const int* info,
+                              int nranges, const int* lo, const int* hi, const int* slot, cplx* out, cplx* part);
 // nested refinement on the device (density.py:239-268): see refine_levels_kernel
 constexpr int REF_MAX_LEVELS = 2048, REF_MAX_INTS = 64, REF_MAX_N = 512;
 void launch_refine_levels(hipStream_t st, int n2, int nint, const cplx* sums, const int* first, const double* ratio, double tol,
