@@ -36,7 +36,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/n50
 step "c5 trace, scf, c4, shares"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/c5 -- python $R/bench.py --config c5 --steps 1 --warmup 1 > $P/c5.json 2> $P/c5.err; echo "c5 trace exit=$?"
 cd $R
-timeout -k 10 900 python bench.py --config scf --steps 3 > $P/scf.json 2> $P/scf.err; echo "scf exit=$?"
+timeout -k 10 900 python bench.py --config scf --steps 5 > $P/scf.json 2> $P/scf.err; echo "scf exit=$?"
 timeout -k 10 300 python bench.py --config c4 --steps 5 > $P/c4.json 2> $P/c4.err; echo "c4 exit=$?"
 timeout -k 10 300 python bench.py --config c5 --steps 3 --no-cpu > $P/c5_plain.json 2> $P/c5_plain.err; echo "c5 exit=$?"
 timeout -k 10 300 python bench.py --config c4 --steps 5 --emulate-share 8 > $P/c4_share8.json 2> $P/c4_share8.err; echo "c4 share exit=$?"
