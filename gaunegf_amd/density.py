@@ -230,6 +230,7 @@ def integrateJointlyAdaptiveANT(node_grids, computeSegments, tol=ADAPTIVE_INTEGR
 
 
 REFINE_ON_DEVICE = os.environ.get("NEGF_REFINE_ON_DEVICE", "1") != "0"   # adaptive GrInt integrations: update + stopping test in the library
+_CONVERGED_AT = {}          # (provider, tol) -> [level at which the arc / the Fermi tail of the last densityComplex converged]: hints only
 
 
 _LEVEL_GROUPS = {}
@@ -248,13 +249,17 @@ def _level_group(maxN, lo, hi):
     return _LEVEL_GROUPS[key]
 
 
-def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, budget=None):
+def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_GRID_POINTS, budget=None, hints=None):
     """integrateJointlyAdaptiveANT with the refinement itself on the device: every round hands the levels each integration
     is about to visit (up to ``budget`` new nodes, as _adaptive_ant_steps groups them) to ``refine`` -- ONE pass of the
     engine, which applies the reference's update and stopping test level by level (density.py:239-268) and returns the value
     at the level that converged, or after the last one together with the fact that it did not.  What the host no longer does:
     receive a sum per level and run five numpy passes over each.  ``refine`` takes [(E, w, nodes per level, ratio per level,
-    running value or None)] (Engine.gr_int_refine).  Messages as in _adaptive_ant_steps."""
+    running value or None)] (Engine.gr_int_refine).  Messages as in _adaptive_ant_steps.
+    ``hints`` (optional, a list updated in place): per integration the level at which its predecessor converged -- the probes of
+    a Fermi search are neighbours, an integration that converged at 162 nodes last time is not sent the 324 new nodes of the
+    next level ahead of its test again (a third of the points of an N = 60 probe); if it does need them, it asks in a second
+    round.  Only WHAT is evaluated ahead of the test changes, never the result."""
     levels = _ant_levels(maxN)
     if budget is None:
         budget = SPECULATIVE_POINTS
@@ -265,7 +270,8 @@ def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_G
         groups, requests = [], []
         for k in active:
             hi, pts = nxt[k], 0
-            while hi < len(levels) and (hi == nxt[k] or pts + levels[hi][1].size <= budget):
+            cap = len(levels) if hints is None or nxt[k] or hints[k] is None else min(len(levels), hints[k] + 1)
+            while hi < cap and (hi == nxt[k] or pts + levels[hi][1].size <= budget):
                 pts += levels[hi][1].size; hi += 1
             x, w, counts, ratios = _level_group(maxN, nxt[k], hi)
             groups.append((nxt[k], hi))
@@ -275,9 +281,13 @@ def _refine_jointly(node_grids, refine, tol=ADAPTIVE_INTEGRATION_TOL, maxN=MAX_G
             if conv >= 0:
                 print(f'Adaptive integration converged to {maxdps[conv]:.3e} in {levels[lo + conv][0]} points.')
                 result[k] = value
+                if hints is not None:
+                    hints[k] = lo + conv
             elif hi == len(levels):
                 print(f'Adaptive integration reached full grid ({levels[-1][0] / 1} points), final error {maxdps[-1]:.3e}')
                 result[k] = value
+                if hints is not None:
+                    hints[k] = len(levels) - 1
             else:
                 running[k], nxt[k] = value, hi
                 still.append(k)
@@ -536,7 +546,10 @@ def densityComplex(F, S, g, Emin, mu, tol=ADAPTIVE_INTEGRATION_TOL, T=TEMPERATUR
         # the library can run the refinement itself, _refine_jointly: only the refined values come back)
         print('Complex Contour Integration (with the Fermi broadening):')
         if refine is not None:
-            total, tail = _refine_jointly([grid_of(on_arc), grid_of(on_tail)], refine, tol=tol, budget=budget)
+            hints = _CONVERGED_AT.setdefault((id(g), float(tol)), [None, None])
+            if len(_CONVERGED_AT) > 64:
+                _CONVERGED_AT.clear()
+            total, tail = _refine_jointly([grid_of(on_arc), grid_of(on_tail)], refine, tol=tol, budget=budget, hints=hints)
             total = total + tail
         else:
             total, tail = integrateJointlyAdaptiveANT([grid_of(on_arc), grid_of(on_tail)],

@@ -114,6 +114,41 @@ def test_device_side_refinement_driver_equals_the_reference_loop(tol):
     assert max(len(r) for r in rounds) == 2 and any(r == [6, 6] for r in rounds)     # budget 512: every level in one round
 
 
+def test_convergence_hints_only_change_what_is_evaluated_ahead():
+    """density._refine_jointly with ``hints``: the second of two neighbouring integrations is not sent the levels beyond the
+    one its predecessor converged at ahead of its test (and asks for them in a second round if it does need them); values,
+    stopping levels and messages are those of the unhinted run."""
+    rounds = []
+
+    def refine(requests, tol_):
+        rounds.append([sum(r[2]) for r in requests])
+        return _host_refine(requests, tol_)
+    for tol in (1e-3, 1e-6, 1e-9):
+        plain_out, hinted_out = io.StringIO(), io.StringIO()
+        with contextlib.redirect_stdout(plain_out):
+            plain = D._refine_jointly(MAPS, refine, tol=tol, budget=512)
+        hints = [None, None]
+        with contextlib.redirect_stdout(io.StringIO()):
+            D._refine_jointly(MAPS, refine, tol=tol, budget=512, hints=hints)
+        assert all(h is not None and h >= 1 for h in hints)
+        del rounds[:]
+        with contextlib.redirect_stdout(hinted_out):
+            again = D._refine_jointly(MAPS, refine, tol=tol, budget=512, hints=hints)
+        for a, b in zip(plain, again):
+            assert np.array_equal(a, b)
+        assert hinted_out.getvalue() == plain_out.getvalue()
+        nodes_to = lambda j: sum(lv[1].size for lv in D._ant_levels(486)[:j + 1])
+        assert rounds == [[nodes_to(hints[0]), nodes_to(hints[1])]]                 # one round, exactly the levels needed
+    # a hint that is too low costs a second round, not the result
+    low = [1, 1]
+    del rounds[:]
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = D._refine_jointly(MAPS, refine, tol=1e-9, budget=512, hints=low)
+    for a, b in zip(plain, got):                                                  # (plain: the tol = 1e-9 run above)
+        assert np.array_equal(a, b)
+    assert len(rounds) == 2 and rounds[0] == [6, 6]
+
+
 def test_grids_of_the_refined_path_equal_the_level_by_level_grids_bitwise(monkeypatch):
     """density._refine_jointly evaluates an integration's node -> energy map ONCE on the concatenated nodes of the levels it
     requests.  Every map is elementwise: each node must get, bit for bit, the energy and the weight it gets when the levels are
